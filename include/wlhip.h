@@ -1,0 +1,184 @@
+/* wlhip.h -- C ABI of libwlhip.so, the MI355X-native backend for WaterLily's `sim_step!` hot path.
+ *
+ * This header is the drop-in boundary.  Every entry point replaces one method of the reference
+ * (/root/reference, file:line cited per function) that a `mem=<device array>` backend overrides at
+ * function granularity (precedent: ext/WaterLilyAMDGPUExt.jl:24).
+ * The reference-side binding (a Julia package extension made of `ccall`s) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes, doubles; no C++/torch types; every function returns
+ *     0 on success or a non-zero code (hipError_t, or WL_E_* below); wl_last_error() gives the text.
+ *   - arrays follow the reference layout (src/Flow.jl:112-118): column-major, ONE ghost layer per side,
+ *     vector fields as separate component blocks (SoA).  Strides are explicit (wl_grid), so both the dense
+ *     Julia layout (s = {1, n0, n0*n1}, sc = n0*n1*n2) and a padded/aligned allocation are accepted.
+ *   - directions/components are 0-based; `perdir_mask` bit j set = direction j periodic
+ *     (reference: 1-based tuple `perdir`).
+ *   - scalars cross the ABI as double and are rounded to the field type T where the reference holds a T.
+ *   - all work is enqueued on one HIP stream (wl_set_stream; default: the null stream).  Functions that
+ *     return a scalar synchronise that stream; all others are asynchronous.
+ *   - the caller owns every field array; handles own only internal scratch (reduction partials, solver
+ *     scalars).  Aliasing required by the reference is honoured: pois.x === flow.p, pois.L === flow.mu0,
+ *     pois.z === flow.sigma (src/WaterLily.jl:77) -- pass the same pointers.
+ */
+#ifndef WLHIP_H
+#define WLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WL_ABI_VERSION 1
+
+typedef enum wl_dtype { WL_F32 = 0, WL_F64 = 1 } wl_dtype;
+
+enum { WL_OK = 0, WL_E_ARG = 10001, WL_E_LEVELS = 10002, WL_E_NOGPU = 10003, WL_E_STATE = 10004 };
+
+/* One grid (= one multigrid level).  n[] INCLUDES the ghost layer (src/Flow.jl:112 `Ng = N .+ 2`). */
+typedef struct wl_grid {
+    int32_t D;     /* 2 or 3 */
+    int32_t n[3];  /* extents incl. ghosts; n[2] = 1 when D == 2 */
+    int64_t s[3];  /* element strides; s[0] must be 1 */
+    int64_t sc;    /* element stride between the components of a vector field on this grid */
+} wl_grid;
+
+/* ------------------------------------------------------------------ runtime */
+int wl_abi_version(void);
+const char *wl_last_error(void);
+int wl_device_count(int *n);
+int wl_set_device(int dev);
+int wl_set_stream(void *hip_stream); /* hipStream_t; NULL = null stream */
+int wl_sync(void);
+/* device memory for hosts without their own allocator (the Julia shim); torch hosts pass data_ptr() */
+int wl_malloc(void **p, size_t bytes);
+int wl_free(void *p);
+int wl_h2d(void *dst, const void *src, size_t bytes);
+int wl_d2h(void *dst, const void *src, size_t bytes);
+int wl_memset0(void *p, size_t bytes);
+
+/* ------------------------------------------------------------------ util.jl operators */
+/* BC!(a,A,saveexit,perdir)            src/util.jl:192-210 */
+int wl_bc_vec(wl_dtype t, const wl_grid *g, void *a, const double A[3], int saveexit, int perdir_mask);
+/* perBC!(a,perdir)                    src/util.jl:227-231 */
+int wl_bc_per(wl_dtype t, const wl_grid *g, void *a, int perdir_mask);
+/* exitBC!(u,u0,U,dt)                  src/util.jl:216-222 */
+int wl_exit_bc(wl_dtype t, const wl_grid *g, void *u, const void *u0, const double U[3], double dt);
+/* L2(a) = sum(abs2, inside(a))        src/util.jl:68 (ext/WaterLilyAMDGPUExt.jl:24) */
+int wl_L2_inside(wl_dtype t, const wl_grid *g, const void *a, double *out);
+/* dot / sum / maximum over inside(a): LinearAlgebra.dot, Base.sum, Base.maximum as used at
+ * src/Poisson.jl:94,126,131,137,146 and src/Flow.jl:174 (ghost entries are zero there) */
+int wl_dot(wl_dtype t, const wl_grid *g, const void *a, const void *b, double *out);
+int wl_sum(wl_dtype t, const wl_grid *g, const void *a, double *out);
+int wl_max(wl_dtype t, const wl_grid *g, const void *a, double *out);
+
+/* ------------------------------------------------------------------ Flow.jl operators */
+/* conv_diff!(r,u,Phi;nu,perdir)       src/Flow.jl:36-60  (gather form: no Phi scratch needed) */
+int wl_conv_diff(wl_dtype t, const wl_grid *g, void *r, const void *u, double nu, int perdir_mask);
+/* accelerate!(r,dt,g,U)               src/Flow.jl:68-73  (host evaluates g(i,t)+dU_i/dt) */
+int wl_accelerate(wl_dtype t, const wl_grid *g, void *r, const double acc[3]);
+/* BDIM!(a)                            src/Flow.jl:131-135 */
+int wl_bdim(wl_dtype t, const wl_grid *g, void *u, const void *u0, void *f, const void *V, const void *mu0,
+            const void *mu1, double dt);
+/* scale_u!(a,scale)                   src/Flow.jl:170 */
+int wl_scale_u(wl_dtype t, const wl_grid *g, void *u, double scale);
+/* @inside z[I] = div(I,u)             src/Flow.jl:139 (div: :11-17) */
+int wl_div(wl_dtype t, const wl_grid *g, void *z, const void *u);
+/* CFL(a)                              src/Flow.jl:172-182 */
+int wl_cfl(wl_dtype t, const wl_grid *g, void *sigma, const void *u, double nu, double *dt_out);
+
+/* ------------------------------------------------------------------ Poisson.jl / MultiLevelPoisson.jl */
+/* set_diag!(D,iD,L)                   src/Poisson.jl:42-54 */
+int wl_set_diag(wl_dtype t, const wl_grid *g, void *D, void *iD, const void *L);
+/* restrictL!(a,b;perdir)              src/MultiLevelPoisson.jl:26-32 */
+int wl_restrictL(wl_dtype t, const wl_grid *ga, void *a, const wl_grid *gb, const void *b, int perdir_mask);
+/* restrict!(a,b), prolongate!(a,b)    src/MultiLevelPoisson.jl:33-34 */
+int wl_restrict(wl_dtype t, const wl_grid *ga, void *a, const wl_grid *gb, const void *b);
+int wl_prolongate(wl_dtype t, const wl_grid *ga, void *a, const wl_grid *gb, const void *b);
+
+/* One level of the hierarchy = the fields of `Poisson` (src/Poisson.jl:21-30); caller-owned arrays. */
+typedef struct wl_level_desc {
+    wl_grid g;
+    void *L, *D, *iD, *x, *eps, *r, *z;
+} wl_level_desc;
+
+typedef struct wl_mg wl_mg; /* opaque: Poisson (nlevels==1) or MultiLevelPoisson */
+
+/* Poisson(x,L,z) src/Poisson.jl:31-37 / MultiLevelPoisson(x,L,z) src/MultiLevelPoisson.jl:51-59.
+ * The host builds the level shapes (`restrictML`, :18-25) and allocates; create() validates them, fills
+ * the coarse L by restrictL! and D,iD by set_diag!.  nlevels==2 is rejected with WL_E_LEVELS
+ * ("MultiLevelPoisson requires size=a2^n, where n>2"). */
+int wl_mg_create(wl_mg **out, wl_dtype t, int nlevels, const wl_level_desc *levels, int perdir_mask);
+int wl_mg_destroy(wl_mg *m);
+/* update!(ml)                         src/MultiLevelPoisson.jl:62-68 (src/Poisson.jl:46 for one level) */
+int wl_mg_update(wl_mg *m);
+/* mult!(p,x): p.z = A x               src/Poisson.jl:62-68 */
+int wl_mg_mult(wl_mg *m, int level, void *x);
+/* residual!(p)                        src/Poisson.jl:91-97 */
+int wl_mg_residual(wl_mg *m, int level);
+/* increment!(p)                       src/Poisson.jl:99-103 */
+int wl_mg_increment(wl_mg *m, int level);
+/* Jacobi!(p;it)                       src/Poisson.jl:110-113 */
+int wl_mg_jacobi(wl_mg *m, int level, int it);
+/* pcg!(p;it)                          src/Poisson.jl:123-143; n_updates = number of (x,r) updates done */
+int wl_mg_pcg(wl_mg *m, int level, int it, int *n_updates);
+/* L2(p) = r.r                         src/Poisson.jl:146 */
+int wl_mg_L2(wl_mg *m, int level, double *out);
+/* Vcycle!(ml;l)                       src/MultiLevelPoisson.jl:70-82 */
+int wl_mg_vcycle(wl_mg *m, int level);
+/* solver!(p;tol,itmx)                 src/MultiLevelPoisson.jl:87-99 (src/Poisson.jl:162-172 for one
+ * level).  n_iter receives the value the reference pushes onto `p.n`. */
+int wl_mg_solve(wl_mg *m, double tol, int itmx, int *n_iter);
+
+/* ------------------------------------------------------------------ Flow (src/Flow.jl:92-122) */
+typedef struct wl_flow_desc {
+    wl_grid g;
+    void *u, *u0, *f, *p, *sigma, *V, *mu0, *mu1; /* mu1[I,i,j] = component i + D*j */
+    double nu;
+    int32_t exitBC;
+    int32_t perdir_mask;
+} wl_flow_desc;
+
+typedef struct wl_flow wl_flow; /* opaque */
+
+int wl_flow_create(wl_flow **out, wl_dtype t, const wl_flow_desc *desc);
+int wl_flow_destroy(wl_flow *a);
+/* project!(a,b,w)                     src/Flow.jl:137-145 */
+int wl_project(wl_flow *a, wl_mg *b, double dt, double w, int *n_iter);
+/* mom_step!(a,b)                      src/Flow.jl:153-169.  dt = a.dt[end]; U = BCTuple(a.U,a.dt,N);
+ * acc_pred/acc_corr = g(i,t)+dU_i/dt at t=sum(dt[1:end-1]) and t=sum(dt) (NULL when accelerate! is a
+ * no-op, :73).  dt_next receives CFL(a); n_iter[2] the two entries pushed onto pois.n. */
+int wl_mom_step(wl_flow *a, wl_mg *b, double dt, const double U[3], const double *acc_pred,
+                const double *acc_corr, double *dt_next, int n_iter[2]);
+
+/* ------------------------------------------------------------------ Metrics.jl */
+/* pressure_force(p,df,body,t)         src/Metrics.jl:94-100.  nds(body,x,t) (:84-87) runs user closures,
+ * so the host evaluates it once per measure! and hands over the compact band of non-zero entries:
+ * idx[b] = linear element offset of the cell in p (using g->s), nds[b*D + c] = n_c * kern(d), Float64.
+ * out[c] = sum_b Float64( T( p[idx[b]] * nds[b,c] ) ). */
+int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx_dev, const double *nds_dev,
+              int64_t nband, double out[3]);
+
+/* ------------------------------------------------------------------ measurement support */
+/* Kernel classes for launch counting and HIP-event timing (bench.py roofline leg). */
+enum {
+    WL_K_CONVDIFF = 0, WL_K_BDIM = 1, WL_K_BC = 2, WL_K_DIV = 3, WL_K_CORRECT = 4, WL_K_CFL = 5,
+    WL_K_SCALE = 6, WL_K_RESIDUAL = 7, WL_K_JACOBI = 8, WL_K_INCREMENT = 9, WL_K_SMOOTH = 10,
+    WL_K_RESTRICT = 11, WL_K_PROLONG = 12, WL_K_PCG_INIT = 13, WL_K_PCG_MULT = 14, WL_K_PCG_UPDATE = 15,
+    WL_K_PCG_DIR = 16, WL_K_DOT = 17, WL_K_SCALAR = 18, WL_K_SETDIAG = 19, WL_K_RESTRICTL = 20,
+    WL_K_COPY = 21, WL_K_PFORCE = 22, WL_K_MISC = 23, WL_K_COUNT = 24
+};
+const char *wl_kernel_name(int kclass);
+/* time launches of `kclass` (-1 = none) issued for grids with >= min_cells cells, with hipEvents */
+int wl_prof_select(int kclass, int64_t min_cells);
+int wl_prof_reset(void);
+/* launches / cells processed per class since the last reset (all classes, all levels) */
+int wl_prof_counts(int kclass, int64_t *launches, int64_t *cells);
+/* for the selected class: timed launches, their summed cells, summed milliseconds (synchronises) */
+int wl_prof_timed(int64_t *launches, int64_t *cells, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WLHIP_H */

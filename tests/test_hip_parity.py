@@ -1,0 +1,395 @@
+"""GPU parity: every operator of the HIP path (through the C ABI) against the CPU oracle on identical seeded
+inputs, then whole solves / time steps, then the reference's own known-answer tests run on the HIP path.
+
+Tolerances (stated per test):
+  * operators without reductions: BIT-EXACT (both sides round operation by operation, -ffp-contract=off);
+  * operators with reductions (residual!, pcg!, solver!, mom_step!): both sides accumulate in Float64 and
+    round once, only the summation tree differs (~1e-16 relative before rounding), so fields agree to a few
+    ulp of their scale: 1e-5 (f32) / 1e-12 (f64) relative to max|field| -- far inside the north-star budget
+    (u,p within solver tolerance 1e-4 abs on r.r);
+  * iteration counts (pois.n) must be identical.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import wl_oracle as O
+from waterlily_amd import body as B
+from waterlily_amd import sim as S
+from waterlily_amd.body import AutoBody, norm2
+
+TYPES = [np.float32, np.float64]
+SHAPES = [(18, 12), (12, 10, 8)]
+
+
+def rnd(shape, T, seed, lo=-1.0, hi=1.0):
+    rng = np.random.default_rng(seed)
+    return np.asfortranarray((lo + (hi - lo) * rng.random(shape)).astype(T))
+
+
+def field(h: np.ndarray, D: int, padded=True):
+    lay = S.Layout(h.shape[:D], h.dtype, padded)
+    a = lay.alloc(h.shape[D:], "cuda:0")
+    S.upload(a, h)
+    return a
+
+
+def same(a_dev, h, exact=True, tol=0.0):
+    g = S.to_host(a_dev)
+    if exact:
+        assert np.array_equal(g, h), f"max abs diff {np.max(np.abs(g.astype(np.float64) - h))}"
+    else:
+        scale = max(1e-30, float(np.max(np.abs(h))))
+        assert np.max(np.abs(g.astype(np.float64) - h.astype(np.float64))) <= tol * scale
+
+
+def rtol(T):
+    return 1e-5 if np.dtype(T) == np.float32 else 1e-12
+
+
+# ----------------------------------------------------------------------------- util.jl operators
+
+@pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("Ng", SHAPES)
+@pytest.mark.parametrize("padded", [True, False])
+def test_bc_vec_per_exit(T, Ng, padded):
+    D = len(Ng)
+    U = (1.0, 0.5, -0.25)[:D]
+    for saveexit, perdir in [(False, ()), (True, ()), (True, (1,)), (False, (0, D - 1))]:
+        h = rnd(Ng + (D,), T, 1)
+        a = field(h, D, padded)
+        O.BC(h, U, saveexit, perdir)
+        S.BC(a, U, saveexit, perdir)
+        same(a, h)
+    h = rnd(Ng, T, 2)
+    a = field(h, D, padded)
+    O.perBC(h, (0, D - 1))
+    S.perBC(a, (0, D - 1))
+    same(a, h)
+    h, h0 = rnd(Ng + (D,), T, 3), rnd(Ng + (D,), T, 4)
+    a, a0 = field(h, D, padded), field(h0, D, padded)
+    O.exitBC(h, h0, U, 0.3)
+    S.exitBC(a, a0, U, 0.3)
+    same(a, h, exact=False, tol=4 * np.finfo(T).eps)   # mean flux: reduction order
+
+
+# ----------------------------------------------------------------------------- Flow.jl operators
+
+@pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("Ng", SHAPES)
+@pytest.mark.parametrize("perdir", [(), (0,), (1,), "all"])
+def test_conv_diff_bit_exact(T, Ng, perdir):
+    D = len(Ng)
+    perdir = tuple(range(D)) if perdir == "all" else perdir
+    u = rnd(Ng + (D,), T, 5)
+    r, Phi = O.zeros(Ng + (D,), T), O.zeros(Ng, T)
+    O.conv_diff(r, u, Phi, nu=0.05, perdir=perdir)
+    ud, rd = field(u, D), field(rnd(Ng + (D,), T, 6), D)     # r starts as garbage: must be overwritten
+    S.conv_diff(rd, ud, nu=0.05, perdir=perdir)
+    same(rd, r)
+
+
+@pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("Ng", SHAPES)
+def test_accelerate_bdim_scale_div_cfl(T, Ng):
+    D = len(Ng)
+    a_o = O.Flow(tuple(n - 2 for n in Ng), (1.0,) + (0.0,) * (D - 1), T=T, nu=0.01)
+    a_h = S.Flow(tuple(n - 2 for n in Ng), (1.0,) + (0.0,) * (D - 1), T=T, nu=0.01)
+    for k, seed in zip(("u", "u0", "f", "V", "mu0", "mu1"), range(10, 16)):
+        h = rnd(getattr(a_o, k).shape, T, seed)
+        getattr(a_o, k)[...] = h
+        S.upload(getattr(a_h, k), h)
+    acc = (0.3, -0.2, 0.1)[:D]
+    O.accelerate(a_o.f, acc)
+    S.accelerate(a_h.f, acc)
+    same(a_h.f, a_o.f)
+    O.BDIM(a_o)
+    S.BDIM(a_h)
+    same(a_h.f, a_o.f)
+    same(a_h.u, a_o.u)
+    O._fn("wlo_scale_u", T)(O._p(a_o.u), O.C.byref(a_o.grid), 0.5)
+    S.scale_u(a_h, 0.5)
+    same(a_h.u, a_o.u)
+    z = O.zeros(Ng, T)
+    O._fn("wlo_div", T)(O._p(z), O._p(a_o.u), O.C.byref(a_o.grid))
+    zd = field(O.zeros(Ng, T), D)
+    g = a_h.layout.grid()
+    S.check(S._lib.lib().wl_div(S._WLT[np.dtype(T)], S.C.byref(g), S._ptr(zd), S._ptr(a_h.u)))
+    same(zd, z)
+    a_o.sigma[...] = 0   # no stale ghost scratch: the HIP CFL takes the max over inside(sigma)
+    assert O.CFL(a_o) == S.CFL(a_h)
+    assert np.array_equal(S.to_host(a_h.sigma)[O.inside(z)], a_o.sigma[O.inside(z)])
+
+
+# ----------------------------------------------------------------------------- Poisson.jl / MultiLevelPoisson.jl
+
+def make_pois(Ng, T, cls_o, cls_h, perdir=(), padded=True, seed=20):
+    D = len(Ng)
+    L = rnd(Ng + (D,), T, seed, 0.2, 1.0)
+    O.BC(L, (0.0,) * D, False, perdir)
+    x, z = rnd(Ng, T, seed + 1), rnd(Ng, T, seed + 2)
+    z -= z[O.inside(z)].mean().astype(T)
+    xo, Lo, zo = x.copy(order="F"), L.copy(order="F"), z.copy(order="F")
+    po = cls_o(xo, Lo, zo, perdir=perdir)
+    xd, Ld, zd = field(x, D, padded), field(L, D, padded), field(z, D, padded)
+    ph = cls_h(xd, Ld, zd, perdir=perdir)
+    return po, ph
+
+
+def lev_o(po):
+    return po.levels[0] if isinstance(po, O.MultiLevelPoisson) else po
+
+
+def lev_h(ph):
+    return ph.levels[0]
+
+
+@pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("Ng", [(18, 18), (18, 18, 18)])
+@pytest.mark.parametrize("padded", [True, False])
+def test_poisson_operators(T, Ng, padded):
+    po, ph = make_pois(Ng, T, O.MultiLevelPoisson, S.MultiLevelPoisson, padded=padded)
+    assert len(po.levels) == len(ph.levels)
+    for lo, lh in zip(po.levels, ph.levels):            # set_diag!, restrictL!: bit-exact on every level
+        same(lh.L, lo.L)
+        same(lh.D, lo.D)
+        same(lh.iD, lo.iD)
+    xt = rnd(Ng, T, 30)
+    xd = field(xt, len(Ng), padded)
+    O.mult(po, xt)
+    S.mult(ph, xd)
+    same(ph.z, po.z)
+    # residual!: mean shift through a reduction
+    po.z[...] = rnd(Ng, T, 31)
+    S.upload(ph.z, po.z)
+    O.residual(po)
+    S.residual(ph)
+    same(lev_h(ph).r, lev_o(po).r, exact=False, tol=4 * np.finfo(T).eps)
+    S.upload(lev_h(ph).r, lev_o(po).r)                 # re-synchronise, then the pointwise operators are exact
+    O.Jacobi(po)
+    S.Jacobi(ph)
+    same(lev_h(ph).eps, lev_o(po).eps)
+    same(lev_h(ph).r, lev_o(po).r)
+    same(ph.x, po.x)
+    # restrict! / prolongate! between level 1 and 2
+    O.restrict(po.levels[1].r, po.levels[0].r)
+    S.restrict(ph.levels[1].r, ph.levels[0].r)
+    same(ph.levels[1].r, po.levels[1].r)
+    po.levels[1].x[...] = rnd(po.levels[1].x.shape, T, 32)
+    S.upload(ph.levels[1].x, po.levels[1].x)
+    O.prolongate(po.levels[0].eps, po.levels[1].x)
+    S.prolongate(ph.levels[0].eps, ph.levels[1].x)
+    same(lev_h(ph).eps, lev_o(po).eps)
+    O.increment(po)
+    S.increment(ph)
+    same(lev_h(ph).r, lev_o(po).r)
+    same(ph.x, po.x)
+    assert abs(S.L2p(ph) - O.L2p(po)) <= 4 * np.finfo(T).eps * O.L2p(po)
+
+
+@pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("Ng", [(34, 18), (18, 18, 10)])
+def test_pcg_vcycle_solver(T, Ng):
+    po, ph = make_pois(Ng, T, O.MultiLevelPoisson, S.MultiLevelPoisson)
+    O.residual(po)
+    S.residual(ph)
+    n_o, n_h = O.pcg(po), S.pcg(ph)
+    assert n_o == n_h
+    same(lev_h(ph).r, lev_o(po).r, exact=False, tol=rtol(T))
+    same(ph.x, po.x, exact=False, tol=rtol(T))
+    O.Vcycle(po)
+    S.Vcycle(ph)
+    same(lev_h(ph).r, lev_o(po).r, exact=False, tol=rtol(T))
+    same(ph.x, po.x, exact=False, tol=rtol(T))
+    O.solver(po)
+    S.solver(ph)
+    assert po.n == ph.n
+    same(ph.x, po.x, exact=False, tol=10 * rtol(T))
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_single_level_poisson_solver(T):
+    po, ph = make_pois((18, 18), T, O.Poisson, S.Poisson)
+    O.solver(po)
+    S.solver(ph)
+    assert po.n == ph.n
+    same(ph.x, po.x, exact=False, tol=100 * rtol(T))
+
+
+# ----------------------------------------------------------------------------- whole time steps
+
+def pair(dims, u_BC, L, **kw):
+    so = O.Simulation(dims, u_BC, L, measure_fn=B.measure_fields, nds_fn=B.nds_band, **kw)
+    sh = S.Simulation(dims, u_BC, L, **kw)
+    # identical coefficient fields on both sides (host geometry is shared code, but make it explicit)
+    for k in ("mu0", "mu1", "V"):
+        assert np.array_equal(S.to_host(getattr(sh.flow, k)), getattr(so.flow, k))
+    assert np.allclose(S.to_host(sh.flow.u), so.flow.u, rtol=0, atol=4 * np.finfo(so.flow.T).eps)
+    return so, sh
+
+
+def check_step(so, sh, T, nsteps, utol=None):
+    utol = rtol(T) * 50 if utol is None else utol
+    for _ in range(nsteps):
+        O.sim_step(so, remeasure=False)
+        S.sim_step(sh, remeasure=False)
+    assert so.pois.n == sh.pois.n, (so.pois.n, sh.pois.n)
+    assert np.allclose(so.flow.dt, sh.flow.dt, rtol=rtol(T) * 10, atol=0)
+    same(sh.flow.u, so.flow.u, exact=False, tol=utol)
+    same(sh.flow.p, so.flow.p, exact=False, tol=utol * 10)
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_mom_step_2d_circle(T):
+    """BASELINE config C1 shape family: 2-D circle, Re=100 (64x32 here)."""
+    n, m = 64, 32
+    R, c = m / 8, m / 2 - 1
+    body = AutoBody(lambda x, t: norm2(x - c) - R)
+    so, sh = pair((n, m), (1.0, 0.0), 2 * R, nu=2 * R / 100, body=body, T=T)
+    check_step(so, sh, T, 5)
+    fo, fh = O.pressure_force(so), S.pressure_force(sh)
+    assert np.allclose(fo, fh, rtol=1e-4 if T == np.float32 else 1e-9, atol=1e-6 if T == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_mom_step_3d_sphere(T):
+    """BASELINE configs C2/C3 shape family: 3-D sphere, Re=3700, Float32/Float64 (32^3 here)."""
+    m = 32
+    R, c = m / 8, m / 2 - 1
+    body = AutoBody(lambda x, t: norm2(x - c) - R)
+    so, sh = pair((m, m, m), (1.0, 0.0, 0.0), 2 * R, nu=2 * R / 3700, body=body, T=T)
+    check_step(so, sh, T, 3)
+    fo, fh = O.pressure_force(so), S.pressure_force(sh)
+    assert np.allclose(fo, fh, rtol=1e-4 if T == np.float32 else 1e-9, atol=1e-6 if T == np.float32 else 1e-12)
+
+
+def test_mom_step_3d_donut_f64():
+    """BASELINE config C5 shape family: torus AutoBody, Float64."""
+    m = 32
+    c, Rm, rm = m / 2, m / 4, m / 16
+
+    def torus(x, t):
+        q = torch.sqrt((x[1] - c) ** 2 + (x[2] - c) ** 2) - Rm
+        return torch.sqrt((x[0] - c) ** 2 + q ** 2) - rm
+
+    so, sh = pair((m, m, m), (1.0, 0.0, 0.0), Rm, nu=Rm / 1000, body=AutoBody(torus), T=np.float64)
+    check_step(so, sh, np.float64, 3)
+    assert np.allclose(O.pressure_force(so), S.pressure_force(sh), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("exitBC", [False, True])
+def test_mom_step_periodic_exit_accel(exitBC):
+    """periodic direction + exitBC + body force + time-varying U (Flow.jl:58-60,68-73; util.jl:216-222)"""
+    T = np.float64
+    kw = dict(nu=0.01, g=lambda i, t: 0.1 * t if i == 0 else 0.0, perdir=(1,), exitBC=exitBC, T=T, U=1.0)
+    u_BC = lambda i, t: 1.0 + 0.05 * t if i == 0 else 0.0 * t
+    body = AutoBody(lambda x, t: norm2(x - 15.0) - 4.0)
+    so, sh = pair((32, 32), u_BC, 8.0, body=body, **kw)
+    check_step(so, sh, T, 4)
+
+
+# ----------------------------------------------------------------------------- reference known-answer tests on the HIP path
+
+def Poisson_setup(poisson, N, T=np.float32):
+    """maintests.jl:68-79"""
+    D = len(N)
+    c = np.ones(N + (D,), dtype=T, order="F")
+    O.BC(c, (0.0,) * D)
+    x, L, z = field(O.zeros(N, T), D), field(c, D), field(O.zeros(N, T), D)
+    pois = poisson(x, L, z)
+    soln = np.asfortranarray(np.broadcast_to(np.arange(1, N[0] + 1, dtype=T).reshape((-1,) + (1,) * (D - 1)), N).copy())
+    I = (1,) * D
+    soln -= soln[I]
+    S.mult(pois, field(soln, D))
+    S.solver(pois)
+    xh = S.to_host(x)
+    xh -= xh[I]
+    return O.L2(xh - soln) / O.L2(soln), pois
+
+
+def test_ref_poisson_diag_and_iterations():  # maintests.jl:83-92
+    err, pois = Poisson_setup(S.Poisson, (5, 5))
+    Dm = np.array([[0, 0, 0, 0, 0], [0, -2, -3, -2, 0], [0, -3, -4, -3, 0], [0, -2, -3, -2, 0], [0, 0, 0, 0, 0]], np.float32)
+    assert np.array_equal(S.to_host(pois.D), Dm) and err < 1e-5
+    err, pois = Poisson_setup(S.Poisson, (2 ** 6 + 2, 2 ** 6 + 2))
+    assert err < 1e-6 and pois.n[0] < 310
+    err, pois = Poisson_setup(S.Poisson, (2 ** 4 + 2,) * 3)
+    assert err < 1e-6 and pois.n[0] < 35
+
+
+def test_ref_multilevel():  # maintests.jl:99-116
+    with pytest.raises(AssertionError, match="MultiLevelPoisson requires size=a2ⁿ, where n>2"):
+        Poisson_setup(S.MultiLevelPoisson, (15 + 2, 3 ** 4 + 2))
+    err, pois = Poisson_setup(S.MultiLevelPoisson, (10, 10))
+    assert np.array_equal(S.to_host(pois.levels[2].D), np.array([[0, 0, 0, 0], [0, -2, -2, 0], [0, -2, -2, 0], [0, 0, 0, 0]], np.float32))
+    assert err < 1e-5
+    pois.levels[0].L[4:6, :, 0] = 0
+    S.update(pois)
+    assert np.array_equal(S.to_host(pois.levels[2].D), np.array([[0, 0, 0, 0], [0, -1, -1, 0], [0, -1, -1, 0], [0, 0, 0, 0]], np.float32))
+    for T in TYPES:
+        err, pois = Poisson_setup(S.MultiLevelPoisson, (2 ** 6 + 2, 2 ** 6 + 2), T)
+        assert err < 1e-6 and pois.n[0] <= 3
+        err, pois = Poisson_setup(S.MultiLevelPoisson, (2 ** 4 + 2,) * 3, T)
+        assert err < 1e-6 and pois.n[0] <= 3
+
+
+def test_ref_impulsive_flow():  # maintests.jl:172-180
+    U = (2 / 3, -1 / 3)
+    a = S.Flow((16, 16), U, T=np.float32)
+    S.mom_step(a, S.MultiLevelPoisson(a.p, a.mu0, a.sigma))
+    u = S.to_host(a.u)
+    assert O.L2(u[:, :, 0] - np.float32(U[0])) < 2e-5 and O.L2(u[:, :, 1] - np.float32(U[1])) < 1e-5
+
+
+def test_ref_periodic_TGV():  # maintests.jl:232-253
+    L = 64
+    k = 2 * math.pi / L
+    nu = 1 / (k * 1e8)
+
+    def TGV(i, xy, t):
+        x, y = xy[0] * k, xy[1] * k
+        e = np.exp(-2 * k ** 2 * nu * t)
+        return -np.sin(x) * np.cos(y) * e if i == 0 else np.cos(x) * np.sin(y) * e
+
+    s = S.Simulation((L, L), (0, 0), L, U=1, ulam=lambda i, x: TGV(i, x, 0.0), nu=nu, T=np.float32, perdir=(0, 1))
+    S.sim_step(s, math.pi / 100)
+    ue = O.zeros(s.flow.N + (2,), np.float32)
+    O.apply_vec(lambda i, x: TGV(i, x, S.time(s.flow)), ue)
+    u = S.to_host(s.flow.u)
+    assert O.L2(u[:, :, 0] - ue[:, :, 0]) < 1e-4 and O.L2(u[:, :, 1] - ue[:, :, 1]) < 1e-4
+
+
+def test_ref_moving_bodies():  # maintests.jl:391-412 (exitBC=false branch) + sim_time stop rule :387-390
+    radius = 8
+    nu = radius / 250
+    nm = (4 * radius, 4 * radius)
+    circle = lambda x, t: norm2(x - 2.0 * radius) - radius
+    shift = lambda fx: (lambda x, t: x - torch.stack([fx(t), torch.zeros_like(t)])[:, None])
+    s = S.Simulation(nm, (1, 0), radius, body=AutoBody(circle), nu=nu, T=np.float32)
+    assert S.sim_time(s) == 0
+    S.sim_step(s, 0.1, remeasure=False)
+    assert S.sim_time(s) >= 0.1 > sum(s.flow.dt[:-2]) * s.U / s.L
+    s = S.Simulation(nm, (1, 0), radius, body=AutoBody(circle, shift(lambda t: t)), nu=nu, T=np.float32)
+    S.sim_step(s)
+    assert np.allclose(S.to_host(s.flow.u)[:, radius - 1, 0], 1, rtol=1e-3)
+    s = S.Simulation(nm, (0, 0), radius, U=1, body=AutoBody(circle, shift(lambda t: 2 * t ** 2)), nu=nu, T=np.float32)
+    S.sim_step(s)
+    assert s.pois.n == [2, 1]
+    assert float(s.flow.u.max()) > float(s.flow.V.max()) > 0
+
+
+def test_ref_hydrostatic_force():  # maintests.jl:341-346
+    N = 32
+    for T in TYPES:
+        p = O.zeros((N, N), T)
+        p[O.inside(p)] = O.loc(-1, (N, N))[1][O.inside(p)].astype(T)
+        pd = field(p, 2)
+        body = AutoBody(lambda x, t: norm2(x - N / 2) - N // 4)
+        idx, nds = B.nds_band(body, (N - 2, N - 2))
+        force = S.pressure_force_band(pd, *S.band_to_device(pd, idx, nds))
+        assert np.sum(np.abs(force / (math.pi * (N / 4) ** 2) - np.array([0, 1]))) < 2e-3
+        assert np.allclose(force, O.pressure_force_band(p, O.zeros((N, N, 2), T), idx, nds), rtol=1e-12)

@@ -1,0 +1,554 @@
+// wl_api.hip -- C ABI (include/wlhip.h) + host orchestration: Vcycle!, solver!, project!, mom_step!.
+#include <cstdarg>
+#include <cstring>
+
+#include "wl_ops.h"
+
+namespace wl {
+
+Ctx &ctx() {
+    static Ctx c;
+    return c;
+}
+int fail(int code, const char *what, const char *file, int line) {
+    char buf[512];
+    const char *hs = (code > 0 && code < 10000) ? hipGetErrorString((hipError_t)code) : "";
+    snprintf(buf, sizeof buf, "wlhip error %d at %s:%d: %s %s", code, file, line, what, hs);
+    ctx().err = buf;
+    return code ? code : WL_E_ARG;
+}
+
+Prof::Prof(int kclass, int64_t ncells) : ncell(ncells) {
+    Ctx &c = ctx();
+    c.launches[kclass] += 1;
+    c.cells[kclass] += ncells;
+    if (kclass == c.prof_class && ncells >= c.prof_min_cells) {
+        auto get = [&c]() {
+            hipEvent_t e;
+            if (!c.pool.empty()) { e = c.pool.back(); c.pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        a = get(); b = get();
+        timed = true;
+        (void)hipEventRecord(a, c.stream);
+    }
+}
+Prof::~Prof() {
+    if (timed) {
+        Ctx &c = ctx();
+        (void)hipEventRecord(b, c.stream);
+        c.evts.push_back({a, b, ncell});
+    }
+}
+
+int check_grid(const wl_grid *g) {
+    if (!g) return fail(WL_E_ARG, "null grid", __FILE__, __LINE__);
+    if (g->D != 2 && g->D != 3) return fail(WL_E_ARG, "grid.D must be 2 or 3", __FILE__, __LINE__);
+    if (g->s[0] != 1) return fail(WL_E_ARG, "grid.s[0] must be 1", __FILE__, __LINE__);
+    for (int d = 0; d < g->D; ++d)
+        if (g->n[d] < 3) return fail(WL_E_ARG, "grid extents must be >= 3 (one ghost layer per side)", __FILE__, __LINE__);
+    if (g->D == 2 && g->n[2] != 1) return fail(WL_E_ARG, "grid.n[2] must be 1 for D==2", __FILE__, __LINE__);
+    if (g->s[1] < g->n[0]) return fail(WL_E_ARG, "grid.s[1] < n[0]", __FILE__, __LINE__);
+    if (g->D == 3 && g->s[2] < g->s[1] * g->n[1]) return fail(WL_E_ARG, "grid.s[2] < s[1]*n[1]", __FILE__, __LINE__);
+    const int64_t sp = g->D == 3 ? g->s[2] * g->n[2] : g->s[1] * g->n[1];
+    if (g->sc < sp) return fail(WL_E_ARG, "grid.sc smaller than one component", __FILE__, __LINE__);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ handles
+struct Scratch {
+    double *partials = nullptr;  // 4 * WL_MAXB doubles
+    State *st = nullptr;         // device
+    State *hst = nullptr;        // pinned host mirror
+    int init() {
+        WL_HIP(hipMalloc((void **)&partials, sizeof(double) * 4 * WL_MAXB));
+        WL_HIP(hipMalloc((void **)&st, sizeof(State)));
+        WL_HIP(hipMemset(st, 0, sizeof(State)));
+        WL_HIP(hipHostMalloc((void **)&hst, sizeof(State), hipHostMallocDefault));
+        memset(hst, 0, sizeof(State));
+        return 0;
+    }
+    void release() {
+        if (partials) (void)hipFree(partials);
+        if (st) (void)hipFree(st);
+        if (hst) (void)hipHostFree(hst);
+        partials = nullptr; st = nullptr; hst = nullptr;
+    }
+    // bring the device scalars to the host (synchronises the stream)
+    int fetch() {
+        WL_HIP(hipMemcpyAsync(hst, st, sizeof(State), hipMemcpyDeviceToHost, ctx().stream));
+        WL_HIP(hipStreamSynchronize(ctx().stream));
+        return 0;
+    }
+};
+
+Scratch &global_scratch(int *rc) {
+    static Scratch s;
+    static bool ok = false;
+    *rc = 0;
+    if (!ok) { *rc = s.init(); ok = (*rc == 0); }
+    return s;
+}
+
+}  // namespace wl
+
+using namespace wl;
+
+struct wl_mg {
+    wl_dtype t;
+    int D;
+    int nlev;
+    int permask;
+    std::vector<wl_level_desc> lev;
+    Scratch sc;
+};
+struct wl_flow {
+    wl_dtype t;
+    wl_flow_desc d;
+    Scratch sc;
+};
+
+template <class T> static LevelT<T> lvl(const wl_mg *m, int l) {
+    const wl_level_desc &d = m->lev[l];
+    LevelT<T> o;
+    o.g = mkG(&d.g);
+    o.L = (T *)d.L; o.D = (T *)d.D; o.iD = (T *)d.iD; o.x = (T *)d.x; o.eps = (T *)d.eps; o.r = (T *)d.r; o.z = (T *)d.z;
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------ MG orchestration
+template <class T, int D> static int mg_update(wl_mg *m) {
+    {
+        LevelT<T> p = lvl<T>(m, 0);
+        WL_TRY((op_set_diag<T, D>(p.g, p.D, p.iD, p.L)));
+    }
+    for (int l = 1; l < m->nlev; ++l) {
+        LevelT<T> a = lvl<T>(m, l), b = lvl<T>(m, l - 1);
+        WL_TRY((op_restrictL<T, D>(a.g, a.L, b.g, b.L, m->permask)));
+        WL_TRY((op_set_diag<T, D>(a.g, a.D, a.iD, a.L)));
+    }
+    return 0;
+}
+
+// Vcycle!  src/MultiLevelPoisson.jl:70-82
+template <class T, int D> static int mg_vcycle(wl_mg *m, int l) {
+    LevelT<T> fine = lvl<T>(m, l), coarse = lvl<T>(m, l + 1);
+    WL_TRY((op_jacobi<T, D>(fine, 1, m->permask)));
+    WL_TRY((op_restrict<T, D>(coarse.g, coarse.r, fine.g, fine.r)));
+    {
+        Prof p(WL_K_MISC, coarse.g.cells());
+        WL_HIP(hipMemsetAsync(coarse.x, 0, (size_t)span(coarse.g) * sizeof(T), ctx().stream));
+    }
+    if (l + 2 < m->nlev) WL_TRY((mg_vcycle<T, D>(m, l + 1)));
+    WL_TRY((op_pcg<T, D>(coarse, 6, m->permask, m->sc.partials, m->sc.st)));
+    WL_TRY((op_prolongate<T, D>(fine.g, fine.eps, coarse.g, coarse.x)));
+    return op_increment<T, D>(fine, m->permask);
+}
+
+// solver!  src/MultiLevelPoisson.jl:87-99 (nlev>1) / src/Poisson.jl:162-172 (nlev==1).
+// One host synchronisation per iteration: the r2 < tol test (:95).
+template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, int *n_iter) {
+    LevelT<T> p = lvl<T>(m, 0);
+    WL_TRY((op_residual<T, D>(p, m->permask, m->sc.partials, m->sc.st)));
+    int n = 0;
+    while (n < itmx) {
+        if (m->nlev > 1) WL_TRY((mg_vcycle<T, D>(m, 0)));
+        WL_TRY((op_pcg<T, D>(p, 6, m->permask, m->sc.partials, m->sc.st)));
+        WL_TRY((op_L2<T, D>(p, m->sc.partials, m->sc.st)));
+        WL_TRY(m->sc.fetch());
+        ++n;
+        if (m->sc.hst->r2 < tol) break;
+    }
+    WL_TRY((op_bc_per<T, D>(p.g, p.x, m->permask)));
+    if (n_iter) *n_iter = n;
+    return 0;
+}
+
+// project!  src/Flow.jl:137-145
+template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double dt_, double w, int *n_iter) {
+    const G g = mkG(&a->d.g);
+    LevelT<T> p = lvl<T>(b, 0);
+    const bool dbl = (w != 1.0);
+    const double dts = dbl ? w * (double)(T)dt_ : (double)(T)dt_;
+    WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u)));
+    WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
+    WL_TRY((mg_solve<T, D>(b, 1e-4, 32, n_iter)));
+    WL_TRY((op_correct<T, D>(g, (T *)a->d.u, p.L, p.x)));
+    return op_scale_all<T, D>(g, p.x, dts, true, dbl);
+}
+
+// mom_step!  src/Flow.jl:153-169
+template <class T, int D>
+static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const double *gp, const double *gc,
+                         double *dt_next, int *n2) {
+    const wl_flow_desc &d = a->d;
+    const G g = mkG(&d.g);
+    T *u = (T *)d.u, *u0 = (T *)d.u0, *f = (T *)d.f, *V = (T *)d.V, *mu0 = (T *)d.mu0, *mu1 = (T *)d.mu1;
+    const size_t vbytes = (size_t)((long)(D - 1) * g.sc + span(g)) * sizeof(T);
+    {   // a.u0 .= a.u (:154); scale_u!(a,0) is folded into the predictor BDIM (MODE 1)
+        Prof p(WL_K_COPY, g.cells() * D);
+        WL_HIP(hipMemcpyAsync(u0, u, vbytes, hipMemcpyDeviceToDevice, ctx().stream));
+    }
+    // predictor (:157-161): conv_diff! + accelerate! + BDIM! #1 fused, then BDIM! #2
+    WL_TRY((op_conv_diff<T, D, true>(g, f, u0, d.nu, d.perdir_mask, u0, V, dt, gp, gp != nullptr)));
+    WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1)));
+    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
+    if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, u, u0, U, dt, a->sc.partials, a->sc.st)));
+    WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0])));
+    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
+    // corrector (:164-167)
+    WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr)));
+    WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1)));
+    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
+    WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1])));
+    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
+    // push!(a.dt, CFL(a)) (:168)
+    WL_TRY((op_cfl<T, D>(g, (T *)d.sigma, u, d.nu, a->sc.partials, a->sc.st)));
+    WL_TRY(a->sc.fetch());
+    *dt_next = a->sc.hst->out[0];
+    return 0;
+}
+
+template <class T, int D> static int red_L2(const G &g, const T *a, Scratch &S) {
+    return op_reduce<T, D>(g, WL_K_DOT, RED_SUM, 0.0, [=] __device__(long I) { const double v = (double)a[I]; return v * v; },
+                           S.partials, S.st, 0);
+}
+template <class T, int D> static int red_dot(const G &g, const T *a, const T *b, Scratch &S) {
+    return op_reduce<T, D>(g, WL_K_DOT, RED_SUM, 0.0, [=] __device__(long I) { return (double)a[I] * (double)b[I]; },
+                           S.partials, S.st, 0);
+}
+template <class T, int D> static int red_sum(const G &g, const T *a, Scratch &S) {
+    return op_reduce<T, D>(g, WL_K_DOT, RED_SUM, 0.0, [=] __device__(long I) { return (double)a[I]; }, S.partials, S.st, 0);
+}
+template <class T, int D> static int red_max(const G &g, const T *a, Scratch &S) {
+    return op_reduce<T, D>(g, WL_K_DOT, RED_MAX, -1e300, [=] __device__(long I) { return (double)a[I]; }, S.partials, S.st, 0);
+}
+template <class T, int D>
+static int bdim_full(const G &g, T *u, const T *u0, T *f, const T *V, const T *mu0, const T *mu1, double dt) {
+    WL_TRY((op_bdim1<T, D>(g, f, u0, V, dt)));
+    return op_bdim2<T, D, 0>(g, u, f, V, mu0, mu1);
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_pforce(const T *p, const int64_t *idx, const double *nds, int64_t nband, int D,
+                                                 double *partials) {
+    double acc[3] = {0, 0, 0};
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nband; b += (int64_t)gridDim.x * 256) {
+        const double pv = (double)p[idx[b]];
+        for (int c = 0; c < D; ++c) acc[c] += (double)(T)(pv * nds[b * D + c]);  // df[I,:] is a T array
+    }
+    block_red<3>(acc, RED_SUM);
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; ++c) partials[(long)c * gridDim.x + blockIdx.x] = acc[c];
+}
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int wl_abi_version(void) { return WL_ABI_VERSION; }
+const char *wl_last_error(void) { return ctx().err.c_str(); }
+int wl_device_count(int *n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail((int)e, "hipGetDeviceCount", __FILE__, __LINE__); }
+    *n = c;
+    return 0;
+}
+int wl_set_device(int dev) { WL_HIP(hipSetDevice(dev)); return 0; }
+int wl_set_stream(void *s) { ctx().stream = (hipStream_t)s; return 0; }
+int wl_sync(void) { WL_HIP(hipStreamSynchronize(ctx().stream)); return 0; }
+int wl_malloc(void **p, size_t bytes) { WL_HIP(hipMalloc(p, bytes)); return 0; }
+int wl_free(void *p) { WL_HIP(hipFree(p)); return 0; }
+int wl_h2d(void *dst, const void *src, size_t bytes) {
+    WL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
+    WL_HIP(hipStreamSynchronize(ctx().stream));
+    return 0;
+}
+int wl_d2h(void *dst, const void *src, size_t bytes) {
+    WL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().stream));
+    WL_HIP(hipStreamSynchronize(ctx().stream));
+    return 0;
+}
+int wl_memset0(void *p, size_t bytes) { WL_HIP(hipMemsetAsync(p, 0, bytes, ctx().stream)); return 0; }
+
+#define WL_GS()                                  \
+    WL_TRY(check_grid(g));                       \
+    int rc__ = 0;                                \
+    Scratch &S = global_scratch(&rc__);          \
+    (void)S;                                     \
+    WL_TRY(rc__);                                \
+    const G gg = mkG(g)
+
+int wl_bc_vec(wl_dtype t, const wl_grid *g, void *a, const double A[3], int saveexit, int perdir_mask) {
+    WL_GS();
+    WL_DISPATCH(t, g->D, (op_bc_vec<T, DD>(gg, (T *)a, A, saveexit, perdir_mask)));
+}
+int wl_bc_per(wl_dtype t, const wl_grid *g, void *a, int perdir_mask) {
+    WL_GS();
+    WL_DISPATCH(t, g->D, (op_bc_per<T, DD>(gg, (T *)a, perdir_mask)));
+}
+int wl_exit_bc(wl_dtype t, const wl_grid *g, void *u, const void *u0, const double U[3], double dt) {
+    WL_GS();
+    WL_DISPATCH(t, g->D, (op_exit_bc<T, DD>(gg, (T *)u, (const T *)u0, U, dt, S.partials, S.st)));
+}
+
+#define WL_RED(CALL)                 \
+    do {                             \
+        int r1__ = [&]() -> int { WL_DISPATCH(t, g->D, CALL); }(); \
+        if (r1__) return r1__;       \
+        WL_TRY(S.fetch());           \
+        *out = S.hst->out[0];        \
+        return 0;                    \
+    } while (0)
+
+int wl_L2_inside(wl_dtype t, const wl_grid *g, const void *a, double *out) {
+    WL_GS();
+    WL_RED((red_L2<T, DD>(gg, (const T *)a, S)));
+}
+int wl_dot(wl_dtype t, const wl_grid *g, const void *a, const void *b, double *out) {
+    WL_GS();
+    WL_RED((red_dot<T, DD>(gg, (const T *)a, (const T *)b, S)));
+}
+int wl_sum(wl_dtype t, const wl_grid *g, const void *a, double *out) {
+    WL_GS();
+    WL_RED((red_sum<T, DD>(gg, (const T *)a, S)));
+}
+int wl_max(wl_dtype t, const wl_grid *g, const void *a, double *out) {
+    WL_GS();
+    WL_RED((red_max<T, DD>(gg, (const T *)a, S)));
+}
+
+int wl_conv_diff(wl_dtype t, const wl_grid *g, void *r, const void *u, double nu, int perdir_mask) {
+    WL_GS();
+    WL_DISPATCH(t, g->D, (op_conv_diff<T, DD, false>(gg, (T *)r, (const T *)u, nu, perdir_mask, nullptr, nullptr, 0.0,
+                                                      nullptr, false)));
+}
+int wl_accelerate(wl_dtype t, const wl_grid *g, void *r, const double acc[3]) {
+    WL_GS();
+    WL_DISPATCH(t, g->D, (op_accelerate<T, DD>(gg, (T *)r, acc)));
+}
+int wl_bdim(wl_dtype t, const wl_grid *g, void *u, const void *u0, void *f, const void *V, const void *mu0,
+            const void *mu1, double dt) {
+    WL_GS();
+    WL_DISPATCH(t, g->D, (bdim_full<T, DD>(gg, (T *)u, (const T *)u0, (T *)f, (const T *)V, (const T *)mu0,
+                                           (const T *)mu1, dt)));
+}
+int wl_scale_u(wl_dtype t, const wl_grid *g, void *u, double scale) {
+    WL_GS();
+    WL_DISPATCH(t, g->D, (op_scale_u<T, DD>(gg, (T *)u, scale)));
+}
+int wl_div(wl_dtype t, const wl_grid *g, void *z, const void *u) {
+    WL_GS();
+    WL_DISPATCH(t, g->D, (op_div<T, DD>(gg, (T *)z, (const T *)u)));
+}
+int wl_cfl(wl_dtype t, const wl_grid *g, void *sigma, const void *u, double nu, double *out) {
+    WL_GS();
+    WL_RED((op_cfl<T, DD>(gg, (T *)sigma, (const T *)u, nu, S.partials, S.st)));
+}
+int wl_set_diag(wl_dtype t, const wl_grid *g, void *Dg, void *iD, const void *L) {
+    WL_GS();
+    WL_DISPATCH(t, g->D, (op_set_diag<T, DD>(gg, (T *)Dg, (T *)iD, (const T *)L)));
+}
+int wl_restrictL(wl_dtype t, const wl_grid *ga, void *a, const wl_grid *gb, const void *b, int perdir_mask) {
+    WL_TRY(check_grid(ga));
+    WL_TRY(check_grid(gb));
+    const G A = mkG(ga), B = mkG(gb);
+    WL_DISPATCH(t, ga->D, (op_restrictL<T, DD>(A, (T *)a, B, (const T *)b, perdir_mask)));
+}
+int wl_restrict(wl_dtype t, const wl_grid *ga, void *a, const wl_grid *gb, const void *b) {
+    WL_TRY(check_grid(ga));
+    WL_TRY(check_grid(gb));
+    const G A = mkG(ga), B = mkG(gb);
+    WL_DISPATCH(t, ga->D, (op_restrict<T, DD>(A, (T *)a, B, (const T *)b)));
+}
+int wl_prolongate(wl_dtype t, const wl_grid *ga, void *a, const wl_grid *gb, const void *b) {
+    WL_TRY(check_grid(ga));
+    WL_TRY(check_grid(gb));
+    const G A = mkG(ga), B = mkG(gb);
+    WL_DISPATCH(t, ga->D, (op_prolongate<T, DD>(A, (T *)a, B, (const T *)b)));
+}
+
+// ---- multigrid handle
+int wl_mg_create(wl_mg **out, wl_dtype t, int nlevels, const wl_level_desc *levels, int perdir_mask) {
+    if (!out || !levels || nlevels < 1) return fail(WL_E_ARG, "wl_mg_create: bad arguments", __FILE__, __LINE__);
+    if (nlevels == 2) return fail(WL_E_LEVELS, "MultiLevelPoisson requires size=a2^n, where n>2", __FILE__, __LINE__);
+    for (int l = 0; l < nlevels; ++l) {
+        WL_TRY(check_grid(&levels[l].g));
+        const wl_level_desc &d = levels[l];
+        if (!d.L || !d.D || !d.iD || !d.x || !d.eps || !d.r || !d.z)
+            return fail(WL_E_ARG, "wl_mg_create: null level array", __FILE__, __LINE__);
+        if (l > 0)
+            for (int k = 0; k < d.g.D; ++k)
+                if (d.g.n[k] != 1 + levels[l - 1].g.n[k] / 2)  // restrictML, src/MultiLevelPoisson.jl:20
+                    return fail(WL_E_ARG, "wl_mg_create: level extents must be 1+N/2 of the finer level", __FILE__, __LINE__);
+    }
+    wl_mg *m = new wl_mg();
+    m->t = t; m->D = levels[0].g.D; m->nlev = nlevels; m->permask = perdir_mask;
+    m->lev.assign(levels, levels + nlevels);
+    int rc = m->sc.init();
+    if (rc) { delete m; return rc; }
+    rc = wl_mg_update(m);
+    if (rc) { m->sc.release(); delete m; return rc; }
+    *out = m;
+    return 0;
+}
+int wl_mg_destroy(wl_mg *m) {
+    if (!m) return 0;
+    (void)hipStreamSynchronize(ctx().stream);
+    m->sc.release();
+    delete m;
+    return 0;
+}
+#define WL_MG_DISPATCH(CALL) WL_DISPATCH(m->t, m->D, CALL)
+#define WL_LEVEL_OK() \
+    if (!m || level < 0 || level >= m->nlev) return fail(WL_E_ARG, "bad level", __FILE__, __LINE__)
+
+int wl_mg_update(wl_mg *m) { WL_MG_DISPATCH((mg_update<T, DD>(m))); }
+int wl_mg_mult(wl_mg *m, int level, void *x) {
+    WL_LEVEL_OK();
+    WL_MG_DISPATCH((op_mult<T, DD>(lvl<T>(m, level), (T *)x, m->permask)));
+}
+int wl_mg_residual(wl_mg *m, int level) {
+    WL_LEVEL_OK();
+    WL_MG_DISPATCH((op_residual<T, DD>(lvl<T>(m, level), m->permask, m->sc.partials, m->sc.st)));
+}
+int wl_mg_increment(wl_mg *m, int level) {
+    WL_LEVEL_OK();
+    WL_MG_DISPATCH((op_increment<T, DD>(lvl<T>(m, level), m->permask)));
+}
+int wl_mg_jacobi(wl_mg *m, int level, int it) {
+    WL_LEVEL_OK();
+    WL_MG_DISPATCH((op_jacobi<T, DD>(lvl<T>(m, level), it, m->permask)));
+}
+int wl_mg_pcg(wl_mg *m, int level, int it, int *n_updates) {
+    WL_LEVEL_OK();
+    int rc = [&]() -> int { WL_MG_DISPATCH((op_pcg<T, DD>(lvl<T>(m, level), it, m->permask, m->sc.partials, m->sc.st))); }();
+    if (rc) return rc;
+    if (n_updates) {
+        WL_TRY(m->sc.fetch());
+        *n_updates = m->sc.hst->nupd;
+    }
+    return 0;
+}
+int wl_mg_L2(wl_mg *m, int level, double *out) {
+    WL_LEVEL_OK();
+    int rc = [&]() -> int { WL_MG_DISPATCH((op_L2<T, DD>(lvl<T>(m, level), m->sc.partials, m->sc.st))); }();
+    if (rc) return rc;
+    WL_TRY(m->sc.fetch());
+    *out = m->sc.hst->r2;
+    return 0;
+}
+int wl_mg_vcycle(wl_mg *m, int level) {
+    if (!m || level < 0 || level + 1 >= m->nlev) return fail(WL_E_ARG, "bad level", __FILE__, __LINE__);
+    WL_MG_DISPATCH((mg_vcycle<T, DD>(m, level)));
+}
+int wl_mg_solve(wl_mg *m, double tol, int itmx, int *n_iter) {
+    if (!m) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);
+    WL_MG_DISPATCH((mg_solve<T, DD>(m, tol, itmx, n_iter)));
+}
+
+// ---- flow handle
+int wl_flow_create(wl_flow **out, wl_dtype t, const wl_flow_desc *d) {
+    if (!out || !d) return fail(WL_E_ARG, "wl_flow_create: bad arguments", __FILE__, __LINE__);
+    WL_TRY(check_grid(&d->g));
+    if (!d->u || !d->u0 || !d->f || !d->p || !d->sigma || !d->V || !d->mu0 || !d->mu1)
+        return fail(WL_E_ARG, "wl_flow_create: null field", __FILE__, __LINE__);
+    wl_flow *a = new wl_flow();
+    a->t = t; a->d = *d;
+    int rc = a->sc.init();
+    if (rc) { delete a; return rc; }
+    *out = a;
+    return 0;
+}
+int wl_flow_destroy(wl_flow *a) {
+    if (!a) return 0;
+    (void)hipStreamSynchronize(ctx().stream);
+    a->sc.release();
+    delete a;
+    return 0;
+}
+static int check_pair(const wl_flow *a, const wl_mg *b) {
+    if (!a || !b) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);
+    if (a->t != b->t || a->d.g.D != b->D) return fail(WL_E_ARG, "flow/poisson type mismatch", __FILE__, __LINE__);
+    const wl_level_desc &l0 = b->lev[0];
+    // src/WaterLily.jl:77: pois.x === flow.p, pois.L === flow.mu0, pois.z === flow.sigma
+    if (l0.x != a->d.p || l0.L != a->d.mu0 || l0.z != a->d.sigma)
+        return fail(WL_E_ARG, "level-1 (x,L,z) must alias flow (p,mu0,sigma)", __FILE__, __LINE__);
+    for (int k = 0; k < 3; ++k)
+        if (l0.g.n[k] != a->d.g.n[k] || l0.g.s[k] != a->d.g.s[k]) return fail(WL_E_ARG, "flow/poisson grid mismatch", __FILE__, __LINE__);
+    return 0;
+}
+int wl_project(wl_flow *a, wl_mg *b, double dt, double w, int *n_iter) {
+    WL_TRY(check_pair(a, b));
+    WL_DISPATCH(a->t, a->d.g.D, (flow_project<T, DD>(a, b, dt, w, n_iter)));
+}
+int wl_mom_step(wl_flow *a, wl_mg *b, double dt, const double U[3], const double *acc_pred, const double *acc_corr,
+                double *dt_next, int n_iter[2]) {
+    WL_TRY(check_pair(a, b));
+    if (!U || !dt_next || !n_iter) return fail(WL_E_ARG, "wl_mom_step: null output", __FILE__, __LINE__);
+    WL_DISPATCH(a->t, a->d.g.D, (flow_mom_step<T, DD>(a, b, dt, U, acc_pred, acc_corr, dt_next, n_iter)));
+}
+
+// ---- Metrics.jl:94-100
+int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx, const double *nds, int64_t nband,
+              double out[3]) {
+    WL_GS();
+    (void)gg;
+    out[0] = out[1] = out[2] = 0;
+    if (nband <= 0) return 0;
+    int nb = (int)((nband + 255) / 256);
+    if (nb > 1024) nb = 1024;
+    {
+        Prof pr(WL_K_PFORCE, nband);
+        if (t == WL_F32)
+            hipLaunchKernelGGL(k_pforce<float>, dim3(nb), dim3(256), 0, ctx().stream, (const float *)p, idx, nds, nband, g->D, S.partials);
+        else
+            hipLaunchKernelGGL(k_pforce<double>, dim3(nb), dim3(256), 0, ctx().stream, (const double *)p, idx, nds, nband, g->D, S.partials);
+        WL_HIP(hipGetLastError());
+    }
+    State *st = S.st;
+    WL_TRY((launch_finalize<3>(S.partials, nb, RED_SUM, 0.0, [=] __device__(double(&v)[3]) {
+        st->out[0] = v[0]; st->out[1] = v[1]; st->out[2] = v[2]; })));
+    WL_TRY(S.fetch());
+    for (int c = 0; c < g->D; ++c) out[c] = S.hst->out[c];
+    return 0;
+}
+
+// ---- measurement support
+static const char *KNAMES[WL_K_COUNT] = {
+    "conv_diff", "bdim", "bc", "div", "correct", "cfl", "scale", "residual", "jacobi", "increment", "smooth",
+    "restrict", "prolongate", "pcg_init", "pcg_mult_dot", "pcg_update", "pcg_direction", "dot", "scalar", "set_diag",
+    "restrictL", "copy", "pforce", "misc"};
+const char *wl_kernel_name(int k) { return (k >= 0 && k < WL_K_COUNT) ? KNAMES[k] : "?"; }
+int wl_prof_select(int kclass, int64_t min_cells) {
+    ctx().prof_class = kclass;
+    ctx().prof_min_cells = min_cells;
+    return 0;
+}
+int wl_prof_reset(void) {
+    Ctx &c = ctx();
+    for (int k = 0; k < WL_K_COUNT; ++k) { c.launches[k] = 0; c.cells[k] = 0; }
+    for (auto &e : c.evts) { c.pool.push_back(e.a); c.pool.push_back(e.b); }
+    c.evts.clear();
+    return 0;
+}
+int wl_prof_counts(int kclass, int64_t *launches, int64_t *cells) {
+    if (kclass < 0 || kclass >= WL_K_COUNT) return fail(WL_E_ARG, "bad kernel class", __FILE__, __LINE__);
+    *launches = ctx().launches[kclass];
+    *cells = ctx().cells[kclass];
+    return 0;
+}
+int wl_prof_timed(int64_t *launches, int64_t *cells, double *ms) {
+    Ctx &c = ctx();
+    WL_HIP(hipStreamSynchronize(c.stream));
+    int64_t n = 0, nc = 0;
+    double tot = 0;
+    for (auto &e : c.evts) {
+        float t = 0;
+        WL_HIP(hipEventElapsedTime(&t, e.a, e.b));
+        tot += t; ++n; nc += e.cells;
+    }
+    *launches = n; *cells = nc; *ms = tot;
+    return 0;
+}
+
+}  // extern "C"

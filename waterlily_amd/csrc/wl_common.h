@@ -1,0 +1,333 @@
+// wl_common.h -- shared host/device infrastructure of libwlhip (gfx950 only).
+//
+//  * Ctx        : the one stream everything is enqueued on, error text, launch counters, hipEvent timing
+//  * Range      : an index box [lo,hi] and the generic range kernels (the native stand-in for the
+//                 reference's `@loop ... over I in R`, src/util.jl:119-141): 64 lanes of a wavefront
+//                 run along x (unit stride => coalesced), 4 rows per 256-thread workgroup, bounded
+//                 grid-stride so that reductions produce a FIXED number of per-block partials
+//                 (deterministic summation order, no float atomics).
+//  * device math: median/quick/phi/... with the reference's Float32->Float64 promotions
+//                 (src/Flow.jl:1-34); compiled with -ffp-contract=off like the oracle so that each
+//                 operation rounds identically.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/wlhip.h"
+
+namespace wl {
+
+// ------------------------------------------------------------------------------------------ context
+struct TimedEvt { hipEvent_t a, b; int64_t cells; };
+
+struct Ctx {
+    hipStream_t stream = nullptr;
+    std::string err;
+    int64_t launches[WL_K_COUNT] = {0};
+    int64_t cells[WL_K_COUNT] = {0};
+    int prof_class = -1;
+    int64_t prof_min_cells = 0;
+    std::vector<TimedEvt> evts;
+    std::vector<hipEvent_t> pool;
+};
+Ctx &ctx();
+int fail(int code, const char *what, const char *file, int line);
+
+#define WL_HIP(expr)                                                        \
+    do {                                                                    \
+        hipError_t e__ = (expr);                                            \
+        if (e__ != hipSuccess) return ::wl::fail((int)e__, #expr, __FILE__, __LINE__); \
+    } while (0)
+#define WL_TRY(...)                    \
+    do {                               \
+        int r__ = (__VA_ARGS__);       \
+        if (r__ != 0) return r__;      \
+    } while (0)
+#define WL_REQUIRE(cond, msg)                                                  \
+    do {                                                                       \
+        if (!(cond)) return ::wl::fail(WL_E_ARG, msg, __FILE__, __LINE__);     \
+    } while (0)
+
+// RAII bracket: counts the launch, and records hipEvents around it when this class is being timed.
+struct Prof {
+    bool timed = false;
+    hipEvent_t a{}, b{};
+    int64_t ncell;
+    Prof(int kclass, int64_t ncells);
+    ~Prof();
+};
+
+// ------------------------------------------------------------------------------------------ grid
+struct G {  // device-side copy of wl_grid (+ derived values)
+    int D;
+    int n[3];
+    long s[3];
+    long sc;
+    __host__ __device__ long at(int i, int j, int k) const { return (long)i + s[1] * (long)j + s[2] * (long)k; }
+    long cells() const { return (long)n[0] * n[1] * n[2]; }
+    long interior_cells() const {
+        long c = 1;
+        for (int d = 0; d < D; ++d) c *= (long)(n[d] - 2);
+        return c;
+    }
+};
+inline G mkG(const wl_grid *g) {
+    G o;
+    o.D = g->D;
+    for (int d = 0; d < 3; ++d) { o.n[d] = g->n[d]; o.s[d] = g->s[d]; }
+    o.sc = g->sc;
+    return o;
+}
+int check_grid(const wl_grid *g);
+
+struct Range {
+    int lo[3], hi[3];
+    long count() const {
+        long c = 1;
+        for (int d = 0; d < 3; ++d) c *= (long)(hi[d] - lo[d] + 1);
+        return c;
+    }
+};
+inline Range r_inside(const G &g) {  // src/util.jl:47
+    Range r;
+    for (int d = 0; d < 3; ++d) {
+        if (d < g.D) { r.lo[d] = 1; r.hi[d] = g.n[d] - 2; } else { r.lo[d] = r.hi[d] = 0; }
+    }
+    return r;
+}
+inline Range r_whole(const G &g) {
+    Range r;
+    for (int d = 0; d < 3; ++d) { r.lo[d] = 0; r.hi[d] = g.n[d] - 1; }
+    return r;
+}
+// src/util.jl:180-182 slice(dims,i,j,low) with 0-based plane index `i0` and lower bound `low0`
+inline Range r_slice(const G &g, int i0, int j, int low0) {
+    Range r;
+    for (int d = 0; d < 3; ++d) {
+        if (d >= g.D) { r.lo[d] = r.hi[d] = 0; }
+        else if (d == j) { r.lo[d] = r.hi[d] = i0; }
+        else { r.lo[d] = low0; r.hi[d] = g.n[d] - 1; }
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------ launch
+constexpr int WL_BX = 64;    // lanes along the fast axis = one wavefront
+constexpr int WL_BY = 4;     // rows per workgroup
+constexpr int WL_MAXB = 4096;  // grid cap (256 CUs x 16): also the max number of reduction partials
+
+struct Tiling {
+    int a, b, c;       // axis permutation: a = fast axis (first axis with extent > 1)
+    int na, nb, nc;    // extents along a, b, c
+    int nta;           // tiles along a
+    long ntiles;       // nta * ceil(nb*nc / WL_BY)
+    int lo[3];
+};
+inline Tiling mk_tiling(const Range &R) {
+    Tiling t;
+    int ext[3] = {R.hi[0] - R.lo[0] + 1, R.hi[1] - R.lo[1] + 1, R.hi[2] - R.lo[2] + 1};
+    t.a = 0;
+    if (ext[0] == 1) t.a = (ext[1] > 1) ? 1 : (ext[2] > 1 ? 2 : 0);
+    t.b = (t.a + 1) % 3;
+    t.c = (t.a + 2) % 3;
+    if (t.b > t.c) { int x = t.b; t.b = t.c; t.c = x; }
+    t.na = ext[t.a]; t.nb = ext[t.b]; t.nc = ext[t.c];
+    t.nta = (t.na + WL_BX - 1) / WL_BX;
+    long rows = (long)t.nb * t.nc;
+    t.ntiles = (long)t.nta * ((rows + WL_BY - 1) / WL_BY);
+    for (int d = 0; d < 3; ++d) t.lo[d] = R.lo[d];
+    return t;
+}
+inline int grid_for(const Tiling &t) { return (int)(t.ntiles < WL_MAXB ? (t.ntiles < 1 ? 1 : t.ntiles) : WL_MAXB); }
+
+template <class F>
+__global__ __launch_bounds__(WL_BX *WL_BY) void k_range(Tiling t, F f) {
+    const int tx = threadIdx.x & (WL_BX - 1), ty = threadIdx.x / WL_BX;
+    const long rows = (long)t.nb * t.nc;
+    for (long tile = blockIdx.x; tile < t.ntiles; tile += gridDim.x) {
+        const int ta = (int)(tile % t.nta);
+        const long rg = tile / t.nta;
+        const int ia = ta * WL_BX + tx;
+        const long row = rg * WL_BY + ty;
+        if (ia < t.na && row < rows) {
+            int idx[3];
+            idx[t.a] = t.lo[t.a] + ia;
+            idx[t.b] = t.lo[t.b] + (int)(row % t.nb);
+            idx[t.c] = t.lo[t.c] + (int)(row / t.nb);
+            f(idx[0], idx[1], idx[2]);
+        }
+    }
+}
+
+enum RedOp { RED_SUM = 0, RED_MAX = 1 };
+
+__device__ inline double wave_red(double v, int op) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double w = __shfl_down(v, o, 64);
+        v = (op == RED_SUM) ? v + w : (w > v ? w : v);
+    }
+    return v;
+}
+// block reduction of NV values per thread; result valid in thread 0
+template <int NV>
+__device__ inline void block_red(double (&v)[NV], int op) {
+    __shared__ double sm[NV][WL_BY];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double x = wave_red(v[q], op);
+        if (lane == 0) sm[q][w] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            double x = sm[q][0];
+            for (int i = 1; i < WL_BY; ++i) x = (op == RED_SUM) ? x + sm[q][i] : (sm[q][i] > x ? sm[q][i] : x);
+            v[q] = x;
+        }
+    }
+    __syncthreads();
+}
+
+// range kernel whose functor accumulates into NV per-thread doubles: f(i,j,k,acc).
+// partials[q*gridDim.x + blockIdx.x] receives the block's reduction of acc[q].
+template <int NV, class F>
+__global__ __launch_bounds__(WL_BX *WL_BY) void k_range_red(Tiling t, F f, double *partials, int op, double init) {
+    const int tx = threadIdx.x & (WL_BX - 1), ty = threadIdx.x / WL_BX;
+    const long rows = (long)t.nb * t.nc;
+    double acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = init;
+    for (long tile = blockIdx.x; tile < t.ntiles; tile += gridDim.x) {
+        const int ta = (int)(tile % t.nta);
+        const long rg = tile / t.nta;
+        const int ia = ta * WL_BX + tx;
+        const long row = rg * WL_BY + ty;
+        if (ia < t.na && row < rows) {
+            int idx[3];
+            idx[t.a] = t.lo[t.a] + ia;
+            idx[t.b] = t.lo[t.b] + (int)(row % t.nb);
+            idx[t.c] = t.lo[t.c] + (int)(row / t.nb);
+            f(idx[0], idx[1], idx[2], acc);
+        }
+    }
+    block_red<NV>(acc, op);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) partials[(long)q * gridDim.x + blockIdx.x] = acc[q];
+    }
+}
+
+// Final stage: ONE workgroup reduces `np` partials per value in a fixed order, then runs the scalar
+// epilogue `fin(vals)` in thread 0 (device-resident solver scalars: no host round trip).
+template <int NV, class FIN>
+__global__ __launch_bounds__(256) void k_finalize(const double *partials, int np, int op, double init, FIN fin) {
+    double acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double a = init;
+        for (int i = threadIdx.x; i < np; i += 256) {
+            double w = partials[(long)q * np + i];
+            a = (op == RED_SUM) ? a + w : (w > a ? w : a);
+        }
+        acc[q] = a;
+    }
+    block_red<NV>(acc, op);
+    if (threadIdx.x == 0) fin(acc);
+}
+
+template <class F>
+inline int launch_range(int kclass, const Range &R, F f) {
+    if (R.count() <= 0) return 0;
+    Tiling t = mk_tiling(R);
+    Prof p(kclass, R.count());
+    hipLaunchKernelGGL((k_range<F>), dim3(grid_for(t)), dim3(WL_BX * WL_BY), 0, ctx().stream, t, f);
+    return (int)hipGetLastError();
+}
+// returns the number of partials per value through *np
+template <int NV, class F>
+inline int launch_range_red(int kclass, const Range &R, F f, double *partials, int op, double init, int *np) {
+    Tiling t = mk_tiling(R);
+    const int nb = grid_for(t);
+    *np = nb;
+    Prof p(kclass, R.count());
+    hipLaunchKernelGGL((k_range_red<NV, F>), dim3(nb), dim3(WL_BX * WL_BY), 0, ctx().stream, t, f, partials, op, init);
+    return (int)hipGetLastError();
+}
+template <int NV, class FIN>
+inline int launch_finalize(const double *partials, int np, int op, double init, FIN fin) {
+    Prof p(WL_K_SCALAR, 0);
+    hipLaunchKernelGGL((k_finalize<NV, FIN>), dim3(1), dim3(256), 0, ctx().stream, partials, np, op, init, fin);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ device math
+template <class T> struct Lim;
+template <> struct Lim<float> { static constexpr float eps = FLT_EPSILON; };
+template <> struct Lim<double> { static constexpr double eps = DBL_EPSILON; };
+
+// src/Flow.jl:25-34
+template <class T> __host__ __device__ inline T median3(T a, T b, T c) {
+    if (a > b) {
+        if (b >= c) return b;
+        if (a > c) return c;
+    } else {
+        if (b <= c) return b;
+        if (a < c) return c;
+    }
+    return a;
+}
+// src/Flow.jl:4
+template <class T> __host__ __device__ inline T quick(T u, T c, T d) {
+    T a1 = (((T)5 * c + (T)2 * d) - u) / (T)6;
+    T a2 = median3<T>((T)10 * c - (T)9 * u, c, d);
+    return median3<T>(a1, c, a2);
+}
+// src/Flow.jl:3 : T add, then *0.5 in Float64
+template <class T> __device__ inline double phi(const T *f, long I, long s) { return (double)(T)(f[I] + f[I - s]) * 0.5; }
+// src/Flow.jl:6
+template <class T> __device__ inline double phiu(const T *f, long I, long s, double u) {
+    return u > 0 ? u * (double)quick<T>(f[I - 2 * s], f[I - s], f[I]) : u * (double)quick<T>(f[I + s], f[I], f[I - s]);
+}
+// src/Flow.jl:7
+template <class T> __device__ inline double phiuP(const T *f, long Ip, long I, long s, double u) {
+    return u > 0 ? u * (double)quick<T>(f[Ip], f[I - s], f[I]) : u * (double)quick<T>(f[I + s], f[I], f[I - s]);
+}
+// src/Flow.jl:8
+template <class T> __device__ inline double phiuL(const T *f, long I, long s, double u) {
+    return u > 0 ? u * phi<T>(f, I, s) : u * (double)quick<T>(f[I + s], f[I], f[I - s]);
+}
+// src/Flow.jl:9
+template <class T> __device__ inline double phiuR(const T *f, long I, long s, double u) {
+    return u < 0 ? u * phi<T>(f, I, s) : u * (double)quick<T>(f[I - 2 * s], f[I - s], f[I]);
+}
+// src/Poisson.jl:69-75 mult(I,L,D,x)
+template <class T, int D> __device__ inline T mult1(const G &g, const T *L, const T *Dg, const T *x, long I) {
+    T s = x[I] * Dg[I];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const long sd = g.s[d];
+        const T *Ld = L + (long)d * g.sc;
+        s += x[I - sd] * Ld[I] + x[I + sd] * Ld[I + sd];
+    }
+    return s;
+}
+
+// dispatch on (dtype, D)
+#define WL_DISPATCH(t, D, CALL)                                          \
+    do {                                                                 \
+        if ((t) == WL_F32 && (D) == 3) { using T = float; constexpr int DD = 3; return CALL; }   \
+        if ((t) == WL_F32 && (D) == 2) { using T = float; constexpr int DD = 2; return CALL; }   \
+        if ((t) == WL_F64 && (D) == 3) { using T = double; constexpr int DD = 3; return CALL; }  \
+        if ((t) == WL_F64 && (D) == 2) { using T = double; constexpr int DD = 2; return CALL; }  \
+        return ::wl::fail(WL_E_ARG, "unsupported dtype/dimension", __FILE__, __LINE__);          \
+    } while (0)
+
+}  // namespace wl

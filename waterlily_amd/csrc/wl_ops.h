@@ -1,0 +1,554 @@
+// wl_ops.h -- operator templates (one per reference operator), gfx950.
+//
+// v1 kernels: one thread per cell through the generic range kernels of wl_common.h; x is the unit-stride
+// axis so every wavefront reads/writes 64 consecutive elements (coalesced 256-B/512-B segments); stencil
+// neighbours are served by L1/L2 (per-XCD) and the 256 MiB Infinity Cache.  All per-cell arithmetic
+// follows the reference operation by operation (citations per function) including its Float64
+// promotions, so results match the CPU oracle to the last bit wherever no reduction is involved.
+#pragma once
+#include "wl_common.h"
+
+namespace wl {
+
+// device-resident solver scalars (no host round trip inside pcg!/residual!)
+struct State {
+    double rho, alpha, beta;  // pcg scalars, each holding a value already rounded to T
+    double shift;             // residual! mean
+    double r2;                // L2(p)
+    double out[4];            // generic scalar outputs (cfl dt, dot, sum, ...)
+    int active;               // pcg still running
+    int do_shift;             // residual! must subtract the mean
+    int nupd;                 // number of (x,r) updates pcg performed
+    int pad;
+};
+
+template <class T> struct LevelT {
+    G g;
+    T *L, *D, *iD, *x, *eps, *r, *z;
+};
+
+inline long span(const G &g) { return g.D == 3 ? (long)g.n[2] * g.s[2] : (long)g.n[1] * g.s[1]; }
+
+// ------------------------------------------------------------------------------------------ util.jl
+// BC!(a,A,saveexit,perdir)  src/util.jl:192-210 -- same sequence of plane loops as the reference, because
+// later planes read ghost values written by earlier ones (edges/corners).
+template <class T, int D>
+int op_bc_vec(const G &g, T *a, const double *A, int saveexit, int permask) {
+    for (int c = 0; c < D; ++c)
+        for (int j = 0; j < D; ++j) {
+            T *ac = a + (long)c * g.sc;
+            const long sj = g.s[j];
+            const int N = g.n[j];
+            const G gg = g;
+            if ((permask >> j) & 1) {
+                const long off = (long)(N - 2) * sj;
+                WL_TRY(launch_range(WL_K_BC, r_slice(g, 0, j, 0), [=] __device__(int i, int jj, int k) {
+                    const long I = gg.at(i, jj, k); ac[I] = ac[I + off]; }));
+                WL_TRY(launch_range(WL_K_BC, r_slice(g, N - 1, j, 0), [=] __device__(int i, int jj, int k) {
+                    const long I = gg.at(i, jj, k); ac[I] = ac[I - off]; }));
+            } else if (c == j) {
+                const T Ac = (T)A[c];
+                for (int s = 0; s < 2; ++s)
+                    WL_TRY(launch_range(WL_K_BC, r_slice(g, s, j, 0), [=] __device__(int i, int jj, int k) {
+                        ac[gg.at(i, jj, k)] = Ac; }));
+                if (!saveexit || c > 0)
+                    WL_TRY(launch_range(WL_K_BC, r_slice(g, N - 1, j, 0), [=] __device__(int i, int jj, int k) {
+                        ac[gg.at(i, jj, k)] = Ac; }));
+            } else {
+                WL_TRY(launch_range(WL_K_BC, r_slice(g, 0, j, 0), [=] __device__(int i, int jj, int k) {
+                    const long I = gg.at(i, jj, k); ac[I] = ac[I + sj]; }));
+                WL_TRY(launch_range(WL_K_BC, r_slice(g, N - 1, j, 0), [=] __device__(int i, int jj, int k) {
+                    const long I = gg.at(i, jj, k); ac[I] = ac[I - sj]; }));
+            }
+        }
+    return 0;
+}
+
+// perBC!(a,perdir)  src/util.jl:227-231
+template <class T, int D>
+int op_bc_per(const G &g, T *a, int permask) {
+    for (int j = 0; j < D; ++j)
+        if ((permask >> j) & 1) {
+            const long off = (long)(g.n[j] - 2) * g.s[j];
+            const G gg = g;
+            WL_TRY(launch_range(WL_K_BC, r_slice(g, 0, j, 0), [=] __device__(int i, int jj, int k) {
+                const long I = gg.at(i, jj, k); a[I] = a[I + off]; }));
+            WL_TRY(launch_range(WL_K_BC, r_slice(g, g.n[j] - 1, j, 0), [=] __device__(int i, int jj, int k) {
+                const long I = gg.at(i, jj, k); a[I] = a[I - off]; }));
+        }
+    return 0;
+}
+
+// exitBC!(u,u0,U,dt)  src/util.jl:216-222
+template <class T, int D>
+int op_exit_bc(const G &g, T *u, const T *u0, const double *U, double dt_, double *partials, State *st) {
+    Range R;
+    for (int d = 0; d < 3; ++d) {
+        if (d >= D) { R.lo[d] = R.hi[d] = 0; }
+        else if (d == 0) { R.lo[d] = R.hi[d] = g.n[0] - 1; }
+        else { R.lo[d] = 1; R.hi[d] = g.n[d] - 2; }
+    }
+    const T U1 = (T)U[0], Udt = U1 * (T)dt_;
+    const G gg = g;
+    int np = 0;
+    WL_TRY((launch_range_red<1>(WL_K_BC, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
+        const long I = gg.at(i, j, k);
+        const T v = u0[I] - Udt * (u0[I] - u0[I - 1]);
+        u[I] = v;
+        acc[0] += (double)v;
+    }, partials, RED_SUM, 0.0, &np)));
+    const T cnt = (T)R.count();
+    WL_TRY((launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) {
+        st->out[0] = (double)((T)v[0] / cnt - U1); })));
+    return launch_range(WL_K_BC, R, [=] __device__(int i, int j, int k) { u[gg.at(i, j, k)] -= (T)st->out[0]; });
+}
+
+// generic interior reductions: dot / sum / max / sum of squares (Float64 accumulation, fixed order)
+template <class T, int D, class F>
+int op_reduce(const G &g, int kclass, int op, double init, F cell, double *partials, State *st, int slot) {
+    int np = 0;
+    const G gg = g;
+    WL_TRY((launch_range_red<1>(kclass, r_inside(g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
+        const double v = cell(gg.at(i, j, k));
+        acc[0] = (op == RED_SUM) ? acc[0] + v : (v > acc[0] ? v : acc[0]);
+    }, partials, op, init, &np)));
+    return launch_finalize<1>(partials, np, op, init, [=] __device__(double(&v)[1]) { st->out[slot] = v[0]; });
+}
+
+// ------------------------------------------------------------------------------------------ Flow.jl
+// conv_diff!(r,u,Phi;nu,perdir)  src/Flow.jl:36-60 in GATHER form: every cell evaluates the fluxes through
+// its own lower and upper faces and applies them in the reference's order (+lower then -upper, j=1..D),
+// each interior flux rounded to T first exactly like the Phi scratch does (:45-47); boundary faces are added
+// in Float64 like :54-55.  No Phi array, no 9x re-read of r, no write race.
+// FUSE: also applies accelerate! (:68-70) and the first BDIM! loop (:133): f = u0 + dt*r - V on ALL cells.
+template <class T, int D, bool FUSE>
+int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T *u0, const T *V, double dt_,
+                 const double *acc, bool has_acc) {
+    const T nu = (T)nu_, dt = (T)dt_;
+    double a3[3] = {0, 0, 0};
+    if (has_acc) for (int d = 0; d < D; ++d) a3[d] = acc[d];
+    const double a0 = a3[0], a1 = a3[1], a2 = a3[2];
+    const G gg = g;
+    return launch_range(WL_K_CONVDIFF, r_whole(g), [=] __device__(int i, int j, int k) {
+        const long I = gg.at(i, j, k);
+        const int idx[3] = {i, j, k};
+        bool lowok = true;
+_Pragma("unroll")
+        for (int d = 0; d < D; ++d) lowok = lowok && idx[d] >= 1;
+_Pragma("unroll")
+        for (int c = 0; c < D; ++c) {
+            const T *ui = u + (long)c * gg.sc;
+            const long si = gg.s[c];
+            T rr = 0;
+            if (lowok) {
+_Pragma("unroll")
+                for (int jd = 0; jd < D; ++jd) {
+                    const int Nj = gg.n[jd];
+                    if (idx[jd] > Nj - 2) continue;
+                    const T *uj = u + (long)jd * gg.sc;
+                    const long sj = gg.s[jd];
+                    const bool per = (permask >> jd) & 1;
+                    {   // lower face of the cell: face index I
+                        const double uf = phi<T>(uj, I, si);
+                        const T nud = nu * (T)(ui[I] - ui[I - sj]);
+                        if (idx[jd] == 1) {
+                            if (!per) {
+                                rr = (T)((double)rr + (phiuL<T>(ui, I, sj, uf) - (double)nud));
+                            } else {
+                                const T P = (T)(phiuP<T>(ui, I + (long)(Nj - 4) * sj, I, sj, uf) - (double)nud);
+                                rr += P;
+                            }
+                        } else {
+                            const T P = (T)(phiu<T>(ui, I, sj, uf) - (double)nud);
+                            rr += P;
+                        }
+                    }
+                    {   // upper face of the cell: face index I+sj
+                        const long J = I + sj;
+                        if (idx[jd] == Nj - 2) {
+                            if (!per) {
+                                const double uf = phi<T>(uj, J, si);
+                                const T nud = nu * (T)(ui[J] - ui[J - sj]);
+                                rr = (T)((double)rr + (-phiuR<T>(ui, J, sj, uf) + (double)nud));
+                            } else {  // :60  r[I-d] -= Phi[CIj(j,I,2)] : the lower-boundary flux, wrapped
+                                const long I2 = I - (long)(idx[jd] - 1) * sj;
+                                const double uf = phi<T>(uj, I2, si);
+                                const T nud = nu * (T)(ui[I2] - ui[I2 - sj]);
+                                const T P = (T)(phiuP<T>(ui, I2 + (long)(Nj - 4) * sj, I2, sj, uf) - (double)nud);
+                                rr -= P;
+                            }
+                        } else {
+                            const double uf = phi<T>(uj, J, si);
+                            const T nud = nu * (T)(ui[J] - ui[J - sj]);
+                            const T P = (T)(phiu<T>(ui, J, sj, uf) - (double)nud);
+                            rr -= P;
+                        }
+                    }
+                }
+            }
+            if (FUSE) {
+                if (has_acc) rr = (T)((double)rr + (c == 0 ? a0 : (c == 1 ? a1 : a2)));
+                r[I + (long)c * gg.sc] = (u0[I + (long)c * gg.sc] + dt * rr) - V[I + (long)c * gg.sc];
+            } else {
+                r[I + (long)c * gg.sc] = rr;
+            }
+        }
+    });
+}
+
+// accelerate!  src/Flow.jl:68-70: r[..,i] .+= g_i on every element
+template <class T, int D>
+int op_accelerate(const G &g, T *r, const double *acc) {
+    const double a0 = acc[0], a1 = acc[1], a2 = D > 2 ? acc[2] : 0.0;
+    const G gg = g;
+    return launch_range(WL_K_MISC, r_whole(g), [=] __device__(int i, int j, int k) {
+        const long I = gg.at(i, j, k);
+_Pragma("unroll")
+        for (int c = 0; c < D; ++c) {
+            T *p = r + I + (long)c * gg.sc;
+            *p = (T)((double)*p + (c == 0 ? a0 : (c == 1 ? a1 : a2)));
+        }
+    });
+}
+
+// first BDIM! loop  src/Flow.jl:133 (all cells)
+template <class T, int D>
+int op_bdim1(const G &g, T *f, const T *u0, const T *V, double dt_) {
+    const T dt = (T)dt_;
+    const G gg = g;
+    return launch_range(WL_K_BDIM, r_whole(g), [=] __device__(int i, int j, int k) {
+        const long I = gg.at(i, j, k);
+_Pragma("unroll")
+        for (int c = 0; c < D; ++c) {
+            const long q = I + (long)c * gg.sc;
+            f[q] = (u0[q] + dt * f[q]) - V[q];
+        }
+    });
+}
+// second BDIM! loop  src/Flow.jl:134 with mu_ddn (:18-24).  MODE 0: u += ...  (the reference statement)
+// MODE 1: predictor, u was zeroed by scale_u!(a,0) (:154) -> u = ... ; MODE 2: corrector, followed by
+// scale_u!(a,0.5) (:166) -> u = 0.5*(u + ...), both roundings kept.
+template <class T, int D, int MODE>
+int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu1) {
+    const G gg = g;
+    return launch_range(WL_K_BDIM, r_inside(g), [=] __device__(int i, int j, int k) {
+        const long I = gg.at(i, j, k);
+_Pragma("unroll")
+        for (int c = 0; c < D; ++c) {
+            const T *fc = f + (long)c * gg.sc;
+            T s = 0;
+_Pragma("unroll")
+            for (int jd = 0; jd < D; ++jd) {
+                const T *m1 = mu1 + (long)(c + D * jd) * gg.sc;
+                s += m1[I] * (fc[I + gg.s[jd]] - fc[I - gg.s[jd]]);
+            }
+            const long q = I + (long)c * gg.sc;
+            const double tmp = (0.5 * (double)s + (double)V[q]) + (double)(T)(mu0[q] * fc[I]);
+            if (MODE == 1) {
+                u[q] = (T)(0.0 + tmp);
+            } else {
+                const T un = (T)((double)u[q] + tmp);
+                u[q] = (MODE == 2) ? (T)((double)un * 0.5) : un;
+            }
+        }
+    });
+}
+
+// scale_u!  src/Flow.jl:170
+template <class T, int D>
+int op_scale_u(const G &g, T *u, double scale) {
+    const G gg = g;
+    return launch_range(WL_K_SCALE, r_inside(g), [=] __device__(int i, int j, int k) {
+        const long I = gg.at(i, j, k);
+_Pragma("unroll")
+        for (int c = 0; c < D; ++c) {
+            T *p = u + I + (long)c * gg.sc;
+            *p = (T)((double)*p * scale);
+        }
+    });
+}
+
+// a .*= s  /  a ./= s over the whole scalar array (src/Flow.jl:139,144).  `dbl`: the scalar is Float64
+// (w = 0.5 makes dt = w*dt a Float64, :138) so the operation is done in Float64 and rounded.
+template <class T, int D>
+int op_scale_all(const G &g, T *a, double s, bool divide, bool dbl) {
+    const G gg = g;
+    const T sT = (T)s;
+    return launch_range(WL_K_SCALE, r_whole(g), [=] __device__(int i, int j, int k) {
+        T *p = a + gg.at(i, j, k);
+        if (dbl) *p = divide ? (T)((double)*p / s) : (T)((double)*p * s);
+        else *p = divide ? *p / sT : *p * sT;
+    });
+}
+
+// @inside z[I] = div(I,u)  src/Flow.jl:11-17,139
+template <class T, int D>
+int op_div(const G &g, T *z, const T *u) {
+    const G gg = g;
+    return launch_range(WL_K_DIV, r_inside(g), [=] __device__(int i, int j, int k) {
+        const long I = gg.at(i, j, k);
+        T s = 0;
+_Pragma("unroll")
+        for (int d = 0; d < D; ++d) s += u[I + gg.s[d] + (long)d * gg.sc] - u[I + (long)d * gg.sc];
+        z[I] = s;
+    });
+}
+
+// u[I,i] -= L[I,i]*d_i x  src/Flow.jl:141-143 (three loops fused: they touch disjoint components)
+template <class T, int D>
+int op_correct(const G &g, T *u, const T *L, const T *x) {
+    const G gg = g;
+    return launch_range(WL_K_CORRECT, r_inside(g), [=] __device__(int i, int j, int k) {
+        const long I = gg.at(i, j, k);
+        const T xc = x[I];
+_Pragma("unroll")
+        for (int d = 0; d < D; ++d) {
+            const long q = I + (long)d * gg.sc;
+            u[q] -= L[q] * (xc - x[I - gg.s[d]]);
+        }
+    });
+}
+
+// CFL  src/Flow.jl:172-182: sigma = flux_out (Float64 via max(0.,.)), dt = min(10, inv(max(sigma)+5nu)).
+// The max runs over inside(sigma): the reference's maximum(a.sigma) also sees ghost cells, which only hold
+// stale flux scratch of conv_diff! (sigma doubles as Phi) -- see DESIGN.md "Deliberate deviations".
+template <class T, int D>
+int op_cfl(const G &g, T *sigma, const T *u, double nu_, double *partials, State *st) {
+    const G gg = g;
+    int np = 0;
+    WL_TRY((launch_range_red<1>(WL_K_CFL, r_inside(g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
+        const long I = gg.at(i, j, k);
+        double s = 0;
+_Pragma("unroll")
+        for (int d = 0; d < D; ++d) {
+            const double a = (double)u[I + gg.s[d] + (long)d * gg.sc], b = -(double)u[I + (long)d * gg.sc];
+            s += (a > 0 ? a : 0.0) + (b > 0 ? b : 0.0);
+        }
+        const T sg = (T)s;
+        sigma[I] = sg;
+        acc[0] = (double)sg > acc[0] ? (double)sg : acc[0];
+    }, partials, RED_MAX, -1e300, &np)));
+    const T nu5 = (T)5 * (T)nu_;
+    return launch_finalize<1>(partials, np, RED_MAX, -1e300, [=] __device__(double(&v)[1]) {
+        const T d = (T)1 / ((T)v[0] + nu5);
+        st->out[0] = (double)(d < (T)10 ? d : (T)10);
+    });
+}
+
+// ------------------------------------------------------------------------------------------ Poisson.jl
+// set_diag!  src/Poisson.jl:42-54 (the two @inside loops fused; same values)
+template <class T, int D>
+int op_set_diag(const G &g, T *Dg, T *iD, const T *L) {
+    const G gg = g;
+    const T eps2 = (T)2 * Lim<T>::eps;
+    return launch_range(WL_K_SETDIAG, r_inside(g), [=] __device__(int i, int j, int k) {
+        const long I = gg.at(i, j, k);
+        T s = 0;
+_Pragma("unroll")
+        for (int d = 0; d < D; ++d) s -= (L[I + (long)d * gg.sc] + L[I + gg.s[d] + (long)d * gg.sc]);
+        Dg[I] = s;
+        iD[I] = (s * s < eps2) ? (T)0 : (T)1 / s;
+    });
+}
+
+// mult!(p,x)  src/Poisson.jl:62-68
+template <class T, int D>
+int op_mult(const LevelT<T> &p, T *x, int permask) {
+    WL_TRY((op_bc_per<T, D>(p.g, x, permask)));
+    WL_HIP(hipMemsetAsync(p.z, 0, (size_t)span(p.g) * sizeof(T), ctx().stream));
+    const LevelT<T> q = p;
+    return launch_range(WL_K_PCG_MULT, r_inside(p.g), [=] __device__(int i, int j, int k) {
+        const long I = q.g.at(i, j, k);
+        q.z[I] = mult1<T, D>(q.g, q.L, q.D, x, I);
+    });
+}
+
+// residual!  src/Poisson.jl:91-97
+template <class T, int D>
+int op_residual(const LevelT<T> &p, int permask, double *partials, State *st) {
+    WL_TRY((op_bc_per<T, D>(p.g, p.x, permask)));
+    const LevelT<T> q = p;
+    int np = 0;
+    WL_TRY((launch_range_red<1>(WL_K_RESIDUAL, r_inside(p.g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
+        const long I = q.g.at(i, j, k);
+        const T v = (q.iD[I] == 0) ? (T)0 : q.z[I] - mult1<T, D>(q.g, q.L, q.D, q.x, I);
+        q.r[I] = v;
+        acc[0] += (double)v;
+    }, partials, RED_SUM, 0.0, &np)));
+    const T cnt = (T)p.g.interior_cells();
+    const T eps2 = (T)2 * Lim<T>::eps;
+    WL_TRY((launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) {
+        const T s = (T)v[0] / cnt;
+        st->shift = (double)s;
+        st->do_shift = !((s < 0 ? -s : s) <= eps2);
+    })));
+    return launch_range(WL_K_RESIDUAL, r_inside(p.g), [=] __device__(int i, int j, int k) {
+        if (!st->do_shift) return;
+        const long I = q.g.at(i, j, k);
+        q.r[I] = q.r[I] - (T)st->shift;
+    });
+}
+
+// increment!  src/Poisson.jl:99-103
+template <class T, int D>
+int op_increment(const LevelT<T> &p, int permask) {
+    WL_TRY((op_bc_per<T, D>(p.g, p.eps, permask)));
+    const LevelT<T> q = p;
+    return launch_range(WL_K_INCREMENT, r_inside(p.g), [=] __device__(int i, int j, int k) {
+        const long I = q.g.at(i, j, k);
+        q.r[I] = q.r[I] - mult1<T, D>(q.g, q.L, q.D, q.eps, I);
+        q.x[I] = q.x[I] + q.eps[I];
+    });
+}
+
+// Jacobi!  src/Poisson.jl:110-113
+template <class T, int D>
+int op_jacobi(const LevelT<T> &p, int it, int permask) {
+    const LevelT<T> q = p;
+    for (int n = 0; n < it; ++n) {
+        WL_TRY(launch_range(WL_K_JACOBI, r_inside(p.g), [=] __device__(int i, int j, int k) {
+            const long I = q.g.at(i, j, k);
+            q.eps[I] = q.r[I] * q.iD[I];
+        }));
+        WL_TRY((op_increment<T, D>(p, permask)));
+    }
+    return 0;
+}
+
+// pcg!  src/Poisson.jl:123-143 with device-resident rho/alpha/beta and the four early exits turned into a
+// device flag: once `active` drops, the remaining (already enqueued) kernels are no-ops, so no host sync.
+// Fusions: [mult + z.eps], [x,r update + z=r*iD + r.z], [direction]; identical per-cell arithmetic.
+template <class T, int D>
+int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st) {
+    const LevelT<T> q = p;
+    const Range R = r_inside(p.g);
+    const T eps10 = (T)10 * Lim<T>::eps;
+    int np = 0;
+    // :125-127
+    WL_TRY((launch_range_red<1>(WL_K_PCG_INIT, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
+        const long I = q.g.at(i, j, k);
+        const T v = q.r[I] * q.iD[I];
+        q.z[I] = v; q.eps[I] = v;
+        acc[0] += (double)q.r[I] * (double)v;
+    }, partials, RED_SUM, 0.0, &np)));
+    WL_TRY((launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) {
+        const T rho = (T)v[0];
+        st->rho = (double)rho;
+        st->nupd = 0;
+        st->active = !((rho < 0 ? -rho : rho) < eps10);
+    })));
+    for (int n = 1; n <= it; ++n) {
+        WL_TRY((op_bc_per<T, D>(p.g, p.eps, permask)));  // :129 (no-op unless periodic)
+        // :130-131
+        WL_TRY((launch_range_red<1>(WL_K_PCG_MULT, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
+            if (!st->active) return;
+            const long I = q.g.at(i, j, k);
+            const T v = mult1<T, D>(q.g, q.L, q.D, q.eps, I);
+            q.z[I] = v;
+            acc[0] += (double)v * (double)q.eps[I];
+        }, partials, RED_SUM, 0.0, &np)));
+        WL_TRY((launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) {
+            if (!st->active) return;
+            const T alpha = (T)st->rho / (T)v[0];
+            const double aa = (double)(alpha < 0 ? -alpha : alpha);
+            st->alpha = (double)alpha;
+            if (aa < 1e-2 || aa > 1e2) st->active = 0;  // :132
+        })));
+        const bool last = (n == it);
+        // :133-137
+        WL_TRY((launch_range_red<1>(WL_K_PCG_UPDATE, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
+            if (!st->active) return;
+            const long I = q.g.at(i, j, k);
+            const T alpha = (T)st->alpha;
+            q.x[I] += alpha * q.eps[I];
+            const T rn = q.r[I] - alpha * q.z[I];
+            q.r[I] = rn;
+            if (!last) {
+                const T zn = rn * q.iD[I];
+                q.z[I] = zn;
+                acc[0] += (double)rn * (double)zn;
+            }
+        }, partials, RED_SUM, 0.0, &np)));
+        WL_TRY((launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) {
+            if (!st->active) return;
+            st->nupd += 1;
+            if (last) { st->active = 0; return; }  // :135
+            const T rho2 = (T)v[0];
+            if ((rho2 < 0 ? -rho2 : rho2) < eps10) { st->active = 0; return; }  // :138
+            st->beta = (double)(rho2 / (T)st->rho);
+            st->rho = (double)rho2;
+        })));
+        if (last) break;
+        // :140
+        WL_TRY(launch_range(WL_K_PCG_DIR, R, [=] __device__(int i, int j, int k) {
+            if (!st->active) return;
+            const long I = q.g.at(i, j, k);
+            q.eps[I] = (T)st->beta * q.eps[I] + q.z[I];
+        }));
+    }
+    return 0;
+}
+
+// L2(p) = r.r  src/Poisson.jl:146 -> st->r2
+template <class T, int D>
+int op_L2(const LevelT<T> &p, double *partials, State *st) {
+    const LevelT<T> q = p;
+    int np = 0;
+    WL_TRY((launch_range_red<1>(WL_K_DOT, r_inside(p.g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
+        const double v = (double)q.r[q.g.at(i, j, k)];
+        acc[0] += v * v;
+    }, partials, RED_SUM, 0.0, &np)));
+    return launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) { st->r2 = (double)(T)v[0]; });
+}
+
+// ------------------------------------------------------------------------------------------ MultiLevelPoisson.jl
+// restrictL!  src/MultiLevelPoisson.jl:10-16,26-32
+template <class T, int D>
+int op_restrictL(const G &ga, T *a, const G &gb, const T *b, int permask) {
+    for (int c = 0; c < D; ++c) {
+        T *ac = a + (long)c * ga.sc;
+        const T *bc = b + (long)c * gb.sc;
+        const G A = ga, B = gb;
+        WL_TRY(launch_range(WL_K_RESTRICTL, r_inside(ga), [=] __device__(int i, int j, int k) {
+            const int cc[3] = {i, j, k};
+            int lo[3], hi[3];
+_Pragma("unroll")
+            for (int d = 0; d < 3; ++d) {
+                if (d >= D) { lo[d] = hi[d] = 0; }
+                else { lo[d] = 2 * cc[d] - 1; hi[d] = (d == c) ? lo[d] : 2 * cc[d]; }
+            }
+            T s = 0;
+            for (int kk = lo[2]; kk <= hi[2]; ++kk)
+                for (int jj = lo[1]; jj <= hi[1]; ++jj)
+                    for (int ii = lo[0]; ii <= hi[0]; ++ii) s += bc[B.at(ii, jj, kk)];
+            ac[A.at(i, j, k)] = (T)(0.5 * (double)s);
+        }));
+    }
+    const double zero[3] = {0, 0, 0};
+    return op_bc_vec<T, D>(ga, a, zero, 0, permask);
+}
+
+// restrict!  src/MultiLevelPoisson.jl:3-9,33 : coarse = SUM of the 2^D children (x fastest)
+template <class T, int D>
+int op_restrict(const G &ga, T *a, const G &gb, const T *b) {
+    const G A = ga, B = gb;
+    return launch_range(WL_K_RESTRICT, r_inside(ga), [=] __device__(int i, int j, int k) {
+        T s = 0;
+        const int k0 = D > 2 ? 2 * k - 1 : 0, k1 = D > 2 ? 2 * k : 0;
+        for (int kk = k0; kk <= k1; ++kk)
+            for (int jj = 2 * j - 1; jj <= 2 * j; ++jj)
+                for (int ii = 2 * i - 1; ii <= 2 * i; ++ii) s += b[B.at(ii, jj, kk)];
+        a[A.at(i, j, k)] = s;
+    });
+}
+
+// prolongate!  src/MultiLevelPoisson.jl:2,34 : fine[I] = coarse[down(I)]
+template <class T, int D>
+int op_prolongate(const G &ga, T *a, const G &gb, const T *b) {
+    const G A = ga, B = gb;
+    return launch_range(WL_K_PROLONG, r_inside(ga), [=] __device__(int i, int j, int k) {
+        a[A.at(i, j, k)] = b[B.at((i + 1) / 2, (j + 1) / 2, D > 2 ? (k + 1) / 2 : 0)];
+    });
+}
+
+}  // namespace wl

@@ -1,0 +1,546 @@
+"""Host-side mirror of the reference's driver API on top of libwlhip.so.
+
+Same names, argument meaning and error behaviour as the reference (file:line relative to /root/reference):
+
+    Flow               src/Flow.jl:92-122            mom_step          src/Flow.jl:153-169
+    Poisson            src/Poisson.jl:21-38          MultiLevelPoisson src/MultiLevelPoisson.jl:44-60
+    Simulation         src/WaterLily.jl:59-79        sim_step/sim_time/measure  src/WaterLily.jl:89-119
+    pressure_force     src/Metrics.jl:94-100
+
+Python-isms: indices, components and periodic directions are 0-based; `!` is dropped from names.
+Fields are torch tensors living in HBM (torch only provides device memory and, for multi-GPU,
+torch.distributed); they are strided *views* shaped like the Julia arrays ((N1,N2[,N3]) scalars,
+(...,D) vectors, (...,D,D) for mu1; one ghost layer) over an allocation whose rows are padded so that the
+first interior element of every row is 128-byte aligned.  All numerics run in the HIP library: there is
+no CPU fallback and construction raises if no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import body as B
+from ._lib import FlowDesc, Grid, LevelDesc, check, d3
+
+_TORCH = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
+_WLT = {np.dtype(np.float32): _lib.WL_F32, np.dtype(np.float64): _lib.WL_F64}
+
+
+def _require_gpu(device) -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.WlError("waterlily_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is False "
+                           "and there is no CPU fallback")
+    dev = torch.device(device)
+    check(_lib.lib().wl_set_device(dev.index or 0))
+    return dev
+
+
+# --------------------------------------------------------------------------- device arrays
+
+class Layout:
+    """Strides of one grid level.  padded=True: row pitch is a multiple of 128 B and the allocation is
+    offset so that element [1,j,k] (first interior cell of a row) is 128-B aligned; padded=False is the
+    reference's dense column-major layout."""
+
+    def __init__(self, Ng: Sequence[int], T, padded: bool = True):
+        self.Ng = tuple(int(n) for n in Ng)
+        self.D = len(self.Ng)
+        self.T = np.dtype(T)
+        n = self.Ng + (1,) * (3 - self.D)
+        al = 128 // self.T.itemsize
+        if padded:
+            self.lead = al - 1
+            sy = -(-n[0] // al) * al
+        else:
+            self.lead = 0
+            sy = n[0]
+        sz = sy * n[1]
+        self.n3 = n
+        self.s = (1, sy, sz)
+        self.span = sz * n[2]
+        self.sc = self.span
+        self.align = al
+
+    def grid(self) -> Grid:
+        g = Grid()
+        g.D = self.D
+        g.n[:] = list(self.n3)
+        g.s[:] = list(self.s)
+        g.sc = self.sc
+        return g
+
+    def alloc(self, ncomp: Sequence[int], device, fill: float = 0.0) -> torch.Tensor:
+        """A zero (or `fill`) field with trailing component dims `ncomp` ((), (D,), (D,D))."""
+        nc = int(np.prod(ncomp)) if len(ncomp) else 1
+        buf = torch.full((self.lead + nc * self.sc + self.align,), fill, dtype=_TORCH[self.T], device=device)
+        size = self.Ng + tuple(ncomp)
+        stride = tuple(self.s[: self.D])
+        cs = self.sc
+        for _ in ncomp:
+            stride += (cs,)
+            cs *= ncomp[0]
+        return torch.as_strided(buf, size, stride, self.lead)
+
+
+def _grid_of(a: torch.Tensor, D: int) -> Grid:
+    """Recover the wl_grid of a strided field view."""
+    g = Grid()
+    g.D = D
+    n = tuple(a.shape[:D]) + (1,) * (3 - D)
+    st = tuple(a.stride()[:D])
+    g.n[:] = list(n)
+    s = list(st) + [st[-1] * n[D - 1]] * (3 - D)
+    g.s[:] = s
+    g.sc = a.stride()[D] if a.ndim > D else s[D - 1] * n[D - 1]
+    return g
+
+
+def _T(a: torch.Tensor) -> np.dtype:
+    return np.dtype(np.float32) if a.dtype == torch.float32 else np.dtype(np.float64)
+
+
+def _ptr(a: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(a.data_ptr())
+
+
+def to_host(a: torch.Tensor) -> np.ndarray:
+    """`Array(field)`: dense Fortran-ordered host copy."""
+    return np.asfortranarray(a.detach().cpu().numpy())
+
+
+def upload(a: torch.Tensor, h: np.ndarray) -> None:
+    """`copyto!(field, host_array)`"""
+    a.copy_(torch.from_numpy(np.ascontiguousarray(h)).to(a.dtype))
+
+
+def permask(perdir: Sequence[int]) -> int:
+    m = 0
+    for j in perdir:
+        m |= 1 << int(j)
+    return m
+
+
+# --------------------------------------------------------------------------- util.jl
+
+def loc(i: int, shape: Sequence[int]) -> np.ndarray:
+    """util.jl:160 for every index of an array of extents `shape` (i=-1: cell centre)."""
+    ax = [np.arange(n, dtype=np.float64) - 0.5 for n in shape]
+    x = np.stack(np.meshgrid(*ax, indexing="ij"))
+    if i >= 0:
+        x[i] -= 0.5
+    return x
+
+
+def apply_vec(f: Callable, c: torch.Tensor) -> None:
+    """util.jl:171 applyV! -- runs the user's closure on the host, then uploads."""
+    D = c.ndim - 1
+    h = np.zeros(tuple(c.shape), dtype=_T(c), order="F")
+    for i in range(D):
+        h[..., i] = np.broadcast_to(np.asarray(f(i, loc(i, c.shape[:-1])), dtype=np.float64), c.shape[:-1])
+    upload(c, h)
+
+
+def inside(a) -> tuple:
+    return tuple(slice(1, n - 1) for n in a.shape)
+
+
+def L2(a: torch.Tensor) -> float:
+    """util.jl:68 (the reference's GPU override: ext/WaterLilyAMDGPUExt.jl:24)"""
+    out = C.c_double()
+    g = _grid_of(a, a.ndim)
+    check(_lib.lib().wl_L2_inside(_WLT[_T(a)], C.byref(g), _ptr(a), C.byref(out)))
+    return out.value
+
+
+def BC(a: torch.Tensor, A, saveexit: bool = False, perdir: Sequence[int] = ()) -> None:
+    """util.jl:192-210"""
+    g = _grid_of(a, a.ndim - 1)
+    check(_lib.lib().wl_bc_vec(_WLT[_T(a)], C.byref(g), _ptr(a), d3(A), int(saveexit), permask(perdir)))
+
+
+def perBC(a: torch.Tensor, perdir: Sequence[int]) -> None:
+    """util.jl:227-231"""
+    g = _grid_of(a, a.ndim)
+    check(_lib.lib().wl_bc_per(_WLT[_T(a)], C.byref(g), _ptr(a), permask(perdir)))
+
+
+def exitBC(u: torch.Tensor, u0: torch.Tensor, U, dt: float) -> None:
+    """util.jl:216-222"""
+    g = _grid_of(u, u.ndim - 1)
+    check(_lib.lib().wl_exit_bc(_WLT[_T(u)], C.byref(g), _ptr(u), _ptr(u0), d3(U), float(dt)))
+
+
+_exit_bc = exitBC
+
+
+def BCTuple(U, dt: Sequence[float], D: int):
+    """Flow.jl:79-80"""
+    if callable(U):
+        t = float(np.sum(np.asarray(dt, dtype=np.float64)))
+        return tuple(float(U(i, t)) for i in range(D))
+    return tuple(float(x) for x in U)
+
+
+def _dUdt(U: Callable, i: int, t: float) -> float:
+    # reference: ForwardDiff.derivative (Flow.jl:71-72); host-side scalar, central difference
+    h = 1e-5 * max(1.0, abs(t))
+    return (float(U(i, t + h)) - float(U(i, t - h))) / (2 * h)
+
+
+def accel_tuple(g, U, dt: Sequence[float], D: int):
+    """Flow.jl:68-73: g(i,t)+dU_i/dt at t=sum(dt); None when accelerate! is a no-op."""
+    if g is None and not callable(U):
+        return None
+    t = float(np.sum(np.asarray(dt, dtype=np.float64)))
+    return tuple((float(g(i, t)) if g is not None else 0.0) + (_dUdt(U, i, t) if callable(U) else 0.0)
+                 for i in range(D))
+
+
+# --------------------------------------------------------------------------- Flow.jl
+
+class Flow:
+    """src/Flow.jl:92-122.  Fields: u, u0, f, V, mu0 (Ng...,D); mu1 (Ng...,D,D); p, sigma (Ng...)."""
+
+    def __init__(self, N, U, *, dt=0.25, nu=0.0, g=None, ulam=None, perdir=(), exitBC=False, T=np.float64,
+                 device="cuda:0", padded=True):
+        self.device = _require_gpu(device)
+        D = len(N)
+        self.D, self.T = D, np.dtype(T)
+        Ng = tuple(int(n) + 2 for n in N)
+        self.N = Ng
+        self.layout = Layout(Ng, T, padded)
+        self.U, self.g, self.nu = U, g, float(nu)
+        self.perdir, self.exitBC = tuple(int(j) for j in perdir), bool(exitBC)
+        self.dt = [float(self.T.type(dt))]
+        al = lambda nc, fill=0.0: self.layout.alloc(nc, self.device, fill)
+        self.u = al((D,))
+        apply_vec(ulam if ulam is not None else (lambda i, x: 0.0), self.u)
+        U0 = BCTuple(U, [0.0], D)
+        BC(self.u, U0, exitBC, perdir)
+        _exit_bc(self.u, self.u, U0, 0.0)
+        self.u0 = al((D,))
+        self.u0.copy_(self.u)
+        self.f, self.p, self.sigma = al((D,)), al(()), al(())
+        self.V, self.mu0, self.mu1 = al((D,)), al((D,), 1.0), al((D, D))
+        BC(self.mu0, (0.0,) * D, False, perdir)
+        desc = FlowDesc()
+        desc.g = self.layout.grid()
+        for k in ("u", "u0", "f", "p", "sigma", "V", "mu0", "mu1"):
+            setattr(desc, k, getattr(self, k).data_ptr())
+        desc.nu, desc.exitBC, desc.perdir_mask = self.nu, int(self.exitBC), permask(self.perdir)
+        self._h = C.c_void_p()
+        check(_lib.lib().wl_flow_create(C.byref(self._h), _WLT[self.T], C.byref(desc)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().wl_flow_destroy(self._h)
+        except Exception:
+            pass
+
+
+def time(a: Flow) -> float:
+    """Flow.jl:129"""
+    return float(np.sum(np.asarray(a.dt[:-1], dtype=np.float64)))
+
+
+def conv_diff(r: torch.Tensor, u: torch.Tensor, Phi=None, nu=0.1, perdir=()):
+    """Flow.jl:36-51 (Phi is accepted for signature parity; the gather kernel needs no scratch)."""
+    g = _grid_of(u, u.ndim - 1)
+    check(_lib.lib().wl_conv_diff(_WLT[_T(u)], C.byref(g), _ptr(r), _ptr(u), float(nu), permask(perdir)))
+
+
+def accelerate(r: torch.Tensor, acc) -> None:
+    g = _grid_of(r, r.ndim - 1)
+    check(_lib.lib().wl_accelerate(_WLT[_T(r)], C.byref(g), _ptr(r), d3(acc)))
+
+
+def BDIM(a: Flow) -> None:
+    """Flow.jl:131-135"""
+    g = a.layout.grid()
+    check(_lib.lib().wl_bdim(_WLT[a.T], C.byref(g), _ptr(a.u), _ptr(a.u0), _ptr(a.f), _ptr(a.V), _ptr(a.mu0),
+                             _ptr(a.mu1), a.dt[-1]))
+
+
+def scale_u(a: Flow, scale: float) -> None:
+    """Flow.jl:170"""
+    g = a.layout.grid()
+    check(_lib.lib().wl_scale_u(_WLT[a.T], C.byref(g), _ptr(a.u), float(scale)))
+
+
+def CFL(a: Flow) -> float:
+    """Flow.jl:172-175"""
+    out = C.c_double()
+    g = a.layout.grid()
+    check(_lib.lib().wl_cfl(_WLT[a.T], C.byref(g), _ptr(a.sigma), _ptr(a.u), a.nu, C.byref(out)))
+    return out.value
+
+
+# --------------------------------------------------------------------------- Poisson.jl / MultiLevelPoisson.jl
+
+class _Level:
+    """One `Poisson` (src/Poisson.jl:21-30): L, D, iD, x, eps, r, z."""
+
+    def __init__(self, lay: Layout, x, L, z, device):
+        self.layout, self.x, self.L, self.z = lay, x, L, z
+        self.D, self.iD, self.eps, self.r = (lay.alloc((), device) for _ in range(4))
+        self.shape = lay.Ng
+
+    def desc(self) -> LevelDesc:
+        d = LevelDesc()
+        d.g = self.layout.grid()
+        for k in ("L", "D", "iD", "x", "eps", "r", "z"):
+            setattr(d, k, getattr(self, k).data_ptr())
+        return d
+
+
+def _layout_of(x: torch.Tensor) -> Layout:
+    D = x.ndim
+    lay = Layout(tuple(x.shape), _T(x), padded=False)
+    st = tuple(x.stride())
+    n = lay.n3
+    lay.s = (1, st[1], st[2] if D == 3 else st[1] * n[1])
+    lay.span = lay.s[2] * n[2]
+    lay.sc = lay.span
+    return lay
+
+
+def _divisible(shape) -> bool:
+    """MultiLevelPoisson.jl:36-37"""
+    return all(n % 2 == 0 and n > 4 for n in shape)
+
+
+class _PoissonBase:
+    def _create(self, levels, perdir):
+        self.levels = levels
+        arr = (LevelDesc * len(levels))(*[l.desc() for l in levels])
+        self._h = C.c_void_p()
+        check(_lib.lib().wl_mg_create(C.byref(self._h), _WLT[self.T], len(levels), arr, permask(perdir)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().wl_mg_destroy(self._h)
+        except Exception:
+            pass
+
+
+class Poisson(_PoissonBase):
+    """src/Poisson.jl:21-38 (single level)"""
+
+    def __init__(self, x: torch.Tensor, L: torch.Tensor, z: torch.Tensor, perdir=()):
+        assert x.shape == z.shape and tuple(L.shape) == tuple(x.shape) + (x.ndim,)
+        self.T = _T(x)
+        self.x, self.L, self.z, self.perdir = x, L, z, tuple(perdir)
+        self.n: list[int] = []
+        lay = _layout_of(x)
+        lay.sc = L.stride(-1)
+        lv = _Level(lay, x, L, z, x.device)
+        self._create([lv], perdir)
+        self.D, self.iD, self.eps, self.r = lv.D, lv.iD, lv.eps, lv.r
+
+
+class MultiLevelPoisson(_PoissonBase):
+    """src/MultiLevelPoisson.jl:44-60"""
+
+    def __init__(self, x: torch.Tensor, L: torch.Tensor, z: torch.Tensor, maxlevels=10, perdir=(), padded=True):
+        assert x.shape == z.shape and tuple(L.shape) == tuple(x.shape) + (x.ndim,)
+        self.T = _T(x)
+        D = x.ndim
+        self.x, self.L, self.z, self.perdir = x, L, z, tuple(perdir)
+        self.n: list[int] = []
+        lay = _layout_of(x)
+        lay.sc = L.stride(-1)
+        levels = [_Level(lay, x, L, z, x.device)]
+        # restrictML, MultiLevelPoisson.jl:18-25,53-55
+        while _divisible(levels[-1].shape) and len(levels) <= maxlevels:
+            Na = tuple(1 + n // 2 for n in levels[-1].shape)
+            la = Layout(Na, self.T, padded)
+            levels.append(_Level(la, la.alloc((), x.device), la.alloc((D,), x.device), la.alloc((), x.device), x.device))
+        if len(levels) <= 2:
+            raise AssertionError("MultiLevelPoisson requires size=a2ⁿ, where n>2")
+        self._create(levels, perdir)
+
+
+def update(p) -> None:
+    """Poisson.jl:46 / MultiLevelPoisson.jl:62-68"""
+    check(_lib.lib().wl_mg_update(p._h))
+
+
+def mult(p, x: torch.Tensor) -> torch.Tensor:
+    """Poisson.jl:62-68"""
+    assert x.shape == p.z.shape and x.stride() == p.z.stride()
+    check(_lib.lib().wl_mg_mult(p._h, 0, _ptr(x)))
+    return p.z
+
+
+def residual(p, level=0):
+    check(_lib.lib().wl_mg_residual(p._h, level))
+
+
+def increment(p, level=0):
+    check(_lib.lib().wl_mg_increment(p._h, level))
+
+
+def Jacobi(p, it=1, level=0):
+    check(_lib.lib().wl_mg_jacobi(p._h, level, it))
+
+
+def pcg(p, it=6, level=0) -> int:
+    n = C.c_int()
+    check(_lib.lib().wl_mg_pcg(p._h, level, it, C.byref(n)))
+    return n.value
+
+
+def L2p(p, level=0) -> float:
+    """Poisson.jl:146"""
+    out = C.c_double()
+    check(_lib.lib().wl_mg_L2(p._h, level, C.byref(out)))
+    return out.value
+
+
+def Vcycle(ml: MultiLevelPoisson, l=0):
+    check(_lib.lib().wl_mg_vcycle(ml._h, l))
+
+
+def solver(p, tol=1e-4, itmx=None):
+    """Poisson.jl:162-172 / MultiLevelPoisson.jl:87-99"""
+    if itmx is None:
+        itmx = 32 if isinstance(p, MultiLevelPoisson) else 1000
+    n = C.c_int()
+    check(_lib.lib().wl_mg_solve(p._h, float(tol), int(itmx), C.byref(n)))
+    p.n.append(n.value)
+
+
+def _two(a, b, D_a, D_b):
+    return _grid_of(a, D_a), _grid_of(b, D_b)
+
+
+def restrict(a: torch.Tensor, b: torch.Tensor):
+    ga, gb = _two(a, b, a.ndim, b.ndim)
+    check(_lib.lib().wl_restrict(_WLT[_T(a)], C.byref(ga), _ptr(a), C.byref(gb), _ptr(b)))
+
+
+def prolongate(a: torch.Tensor, b: torch.Tensor):
+    ga, gb = _two(a, b, a.ndim, b.ndim)
+    check(_lib.lib().wl_prolongate(_WLT[_T(a)], C.byref(ga), _ptr(a), C.byref(gb), _ptr(b)))
+
+
+def restrictL(a: torch.Tensor, b: torch.Tensor, perdir=()):
+    ga, gb = _two(a, b, a.ndim - 1, b.ndim - 1)
+    check(_lib.lib().wl_restrictL(_WLT[_T(a)], C.byref(ga), _ptr(a), C.byref(gb), _ptr(b), permask(perdir)))
+
+
+def project(a: Flow, b: MultiLevelPoisson, w=1.0) -> int:
+    """Flow.jl:137-145"""
+    n = C.c_int()
+    check(_lib.lib().wl_project(a._h, b._h, a.dt[-1], float(w), C.byref(n)))
+    b.n.append(n.value)
+    return n.value
+
+
+def mom_step(a: Flow, b: MultiLevelPoisson) -> None:
+    """Flow.jl:153-169"""
+    U = BCTuple(a.U, a.dt, a.D)
+    gp = accel_tuple(a.g, a.U, a.dt[:-1], a.D)
+    gc = accel_tuple(a.g, a.U, a.dt, a.D)
+    n2 = (C.c_int * 2)()
+    dtn = C.c_double()
+    check(_lib.lib().wl_mom_step(a._h, b._h, a.dt[-1], d3(U), None if gp is None else d3(gp),
+                                 None if gc is None else d3(gc), C.byref(dtn), n2))
+    b.n.extend([int(n2[0]), int(n2[1])])
+    a.dt.append(float(dtn.value))
+
+
+# --------------------------------------------------------------------------- WaterLily.jl
+
+class Simulation:
+    """src/WaterLily.jl:59-79"""
+
+    def __init__(self, dims, u_BC, L, *, dt=0.25, nu=0.0, g=None, U=None, eps=1, perdir=(), ulam=None,
+                 exitBC=False, body=None, T=np.float32, device="cuda:0", padded=True):
+        assert not (callable(u_BC) and callable(ulam)), "`u_BC` and `uλ` cannot be both specified as Function"
+        assert not (U is None and callable(u_BC)), "`U` must be specified if `u_BC` is a Function"
+        if ulam is None:
+            ulam = (lambda i, x: u_BC(i, 0.0)) if callable(u_BC) else (lambda i, x: u_BC[i])
+        self.U = float(np.sqrt(sum(float(v) ** 2 for v in u_BC))) if U is None else U
+        self.L, self.eps = L, eps
+        self.body = body if body is not None else B.NoBody()
+        self.flow = Flow(dims, u_BC, ulam=ulam, dt=dt, nu=nu, g=g, T=T, perdir=perdir, exitBC=exitBC,
+                         device=device, padded=padded)
+        self._band = None
+        measure_flow(self.flow, self.body, t=0.0, eps=eps)
+        self.pois = MultiLevelPoisson(self.flow.p, self.flow.mu0, self.flow.sigma, perdir=perdir, padded=padded)
+
+
+def measure_flow(a: Flow, body, t=0.0, eps=1) -> None:
+    """Body.jl:31-53: the user's sdf/map closures run on the host (body.measure_fields); the coefficient
+    fields are uploaded and the two BC! calls run on the device."""
+    if isinstance(body, B.NoBody):
+        return
+    mu0, mu1, V, d = B.measure_fields(body, tuple(n - 2 for n in a.N), t=t, eps=eps, T=a.T)
+    upload(a.mu0, mu0)
+    upload(a.mu1, mu1)
+    upload(a.V, V)
+    a.sigma[inside(a.sigma)] = torch.from_numpy(np.ascontiguousarray(d[inside(d)])).to(a.sigma.device)
+    BC(a.mu0, (0.0,) * a.D, False, a.perdir)
+    BC(a.V, (0.0,) * a.D, a.exitBC, a.perdir)
+
+
+def sim_time(sim: Simulation) -> float:
+    """WaterLily.jl:89"""
+    return time(sim.flow) * sim.U / sim.L
+
+
+def measure(sim: Simulation, t=None) -> None:
+    """WaterLily.jl:116-119"""
+    t = float(np.sum(np.asarray(sim.flow.dt, dtype=np.float64))) if t is None else t
+    measure_flow(sim.flow, sim.body, t=t, eps=sim.eps)
+    sim._band = None
+    update(sim.pois)
+
+
+def sim_step(sim: Simulation, t_end=None, *, remeasure=True, max_steps=None, verbose=False) -> None:
+    """WaterLily.jl:98-109"""
+    if t_end is None:
+        if remeasure:
+            measure(sim)
+        mom_step(sim.flow, sim.pois)
+        return
+    steps0 = len(sim.flow.dt)
+    while sim_time(sim) < t_end and (max_steps is None or len(sim.flow.dt) - steps0 < max_steps):
+        sim_step(sim, remeasure=remeasure)
+        if verbose:
+            print(f"tU/L={sim_time(sim):.4f}, Δt={sim.flow.dt[-1]:.3f}")
+
+
+def pressure_force_band(p: torch.Tensor, idx: torch.Tensor, nds: torch.Tensor) -> np.ndarray:
+    """Metrics.jl:94-100 with the body term handed over as a compact band (see include/wlhip.h)."""
+    D = p.ndim
+    out = (C.c_double * 3)()
+    g = _grid_of(p, D)
+    check(_lib.lib().wl_pforce(_WLT[_T(p)], C.byref(g), _ptr(p), C.c_void_p(idx.data_ptr()),
+                               C.c_void_p(nds.data_ptr()), idx.numel(), out))
+    return np.array(out[:D])
+
+
+def band_to_device(p: torch.Tensor, idx: np.ndarray, nds: np.ndarray):
+    """Translate dense column-major cell indices (body.nds_band) into element offsets of the strided
+    field `p` and upload both arrays."""
+    D = p.ndim
+    sub = np.unravel_index(idx, tuple(p.shape), order="F")
+    off = sum(s.astype(np.int64) * int(st) for s, st in zip(sub, p.stride()))
+    return (torch.from_numpy(np.ascontiguousarray(off)).to(p.device),
+            torch.from_numpy(np.ascontiguousarray(nds, dtype=np.float64)).to(p.device))
+
+
+def pressure_force(sim: Simulation) -> np.ndarray:
+    """Metrics.jl:94-95"""
+    if sim._band is None or sim._band[0] != time(sim.flow):
+        idx, nds = B.nds_band(sim.body, tuple(n - 2 for n in sim.flow.N), t=time(sim.flow))
+        sim._band = (time(sim.flow),) + band_to_device(sim.flow.p, idx, nds)
+    return pressure_force_band(sim.flow.p, sim._band[1], sim._band[2])
