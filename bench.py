@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- MLUPS (cell-updates/s) per `sim_step!` of the 3-D sphere case (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+
+One "step" = one `sim_step!(sim; remeasure=false)` = one `mom_step!` (predictor + corrector, both pressure
+solves, CFL).  Workload at N=1: BASELINE.json configs[2], the configuration the metric is quoted on:
+3-D sphere, 512^3, Float32, Re=3700, uniform inflow (geometry as README.md:118-125 of the reference).
+Inputs are synthetic and resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+# the GPU box gives one GPU a 16-core CPU share (os.cpu_count() reports the whole host): bound OpenMP to it
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+os.environ.setdefault("OMP_PROC_BIND", "close")
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s float4 copy)
+
+# ALGORITHMIC bytes per processed cell, in units of the element size T (each distinct array element read
+# once + written once; DESIGN.md "kernels and their algorithmic bytes").  Keyed by libwlhip kernel class.
+ALG_T = {
+    "conv_diff": 10.5,      # fused conv_diff!+BDIM#1: read u(3) [+u0(3) in the corrector] + V(3), write f(3): 9T/12T
+    "bdim": 22.5,           # BDIM#2: f(3) V(3) mu0(3) mu1(9) [+u(3) corrector] -> u(3): 21T/24T
+    "pcg_mult_dot": 6.0,    # eps, L(3), D -> z   (+ z.eps partial)
+    "pcg_update": 23.0 / 3, # x, eps, r, z, iD -> x, r, z  (8T; the 6th iteration skips iD/z: 6T)
+    "pcg_direction": 3.0,   # eps, z -> eps
+    "pcg_init": 4.0,        # r, iD -> z, eps
+    "jacobi": 3.0,          # r, iD -> eps
+    "increment": 9.0,       # eps, L(3), D, r, x -> r, x
+    "residual": 8.0,        # x, L(3), D, z, iD -> r
+    "restrict": 9.0,        # per COARSE cell: 8 fine reads + 1 write
+    "prolongate": 2.0,      # per fine cell: 1 write + (1/8) read, rounded up
+    "dot": 1.0,
+    "div": 4.0,
+    "correct": 10.0,        # u(3) rw, L(3), x
+    "scale": 2.0,
+    "cfl": 4.0,
+    "copy": 2.0,            # per element copied: read + write
+}
+
+
+def sphere(n, m, T, Re=3700.0, device="cuda:0"):
+    """reference README.md:118-125: radius=m/8, center=m/2-1, L=2radius, nu=U*L/Re"""
+    from waterlily_amd import sim as S
+    from waterlily_amd.body import AutoBody, norm2
+    radius, center = m / 8, m / 2 - 1
+    body = AutoBody(lambda x, t: norm2(x - center) - radius)
+    return S.Simulation((n, m, m), (1.0, 0.0, 0.0), 2 * radius, nu=2 * radius / Re, body=body, T=T, device=device)
+
+
+def cpu_baseline(size: int, steps: int):
+    """The CPU restatement of the reference (oracle/, OpenMP) timed on the host cores on a bounded sample."""
+    from oracle import wl_oracle as O
+    from waterlily_amd import body as B
+    from waterlily_amd.body import AutoBody, norm2
+    m = size
+    radius, center = m / 8, m / 2 - 1
+    body = AutoBody(lambda x, t: norm2(x - center) - radius)
+    s = O.Simulation((m, m, m), (1.0, 0.0, 0.0), 2 * radius, nu=2 * radius / 3700.0, body=body, T=np.float32,
+                     measure_fn=B.measure_fields, nds_fn=B.nds_band)
+    O.sim_step(s, remeasure=False)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.sim_step(s, remeasure=False)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": m ** 3 * steps / dt / 1e6, "unit": "MLUPS", "cores": cores, "kind": "port",
+            "sample": f"{m}^3 sphere Re=3700 f32, {steps} steps after 1 warm-up, remeasure=false, "
+                      f"V-cycles/step={s.pois.n[-2:]}"}
+
+
+def class_table(L):
+    names = {}
+    k = 0
+    while True:
+        nm = L.wl_kernel_name(k).decode()
+        if nm == "?":
+            break
+        names[nm] = k
+        k += 1
+    return names
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=512, help="cells per side (BASELINE config: 512)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--cpu-size", type=int, default=192)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", default=None, help="force the kernel class reported in `roofline`")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or args.gpus > 1:
+        raise SystemExit("bench.py: the z-slab multi-GPU path is not wired into bench.py yet (round 1: N=1)")
+
+    from waterlily_amd import _lib
+    from waterlily_amd import sim as S
+    L = _lib.lib()
+    T = np.float32 if args.dtype == "f32" else np.float64
+    tsz = np.dtype(T).itemsize
+    dev = f"cuda:{local}"
+    m = args.size
+    sim = sphere(m, m, T, device=dev)
+    ncell = m ** 3
+    names = class_table(L)
+
+    def sync():
+        torch.cuda.synchronize()
+
+    # warm-up; the last warm-up step times EVERY finest-level launch with hipEvents to find the dominant kernel
+    per_class = {}
+    for w in range(args.warmup):
+        S.sim_step(sim, remeasure=False)
+    sync()
+    # each heavy finest-level class is timed with hipEvents in one extra warm-up step to find the dominant kernel
+    heavy = ["pcg_mult_dot", "pcg_update", "pcg_direction", "increment", "conv_diff", "bdim", "residual", "jacobi"]
+    if args.kernel:
+        dominant = args.kernel
+    else:
+        for nm in heavy:
+            _lib.check(L.wl_prof_reset())
+            _lib.check(L.wl_prof_select(names[nm], int(0.9 * ncell)))
+            S.sim_step(sim, remeasure=False)
+            nl, nc, ms = C.c_int64(), C.c_int64(), C.c_double()
+            _lib.check(L.wl_prof_timed(C.byref(nl), C.byref(nc), C.byref(ms)))
+            per_class[nm] = {"launches": nl.value, "ms": ms.value}
+        dominant = max(per_class, key=lambda k: per_class[k]["ms"])
+
+    # timed region: only the dominant class is bracketed by hipEvents (on the library's stream)
+    _lib.check(L.wl_prof_reset())
+    _lib.check(L.wl_prof_select(names[dominant], int(0.9 * ncell)))
+    n0 = len(sim.pois.n)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        S.sim_step(sim, remeasure=False)
+    sync()
+    elapsed = time.perf_counter() - t0
+    nl, nc, ms = C.c_int64(), C.c_int64(), C.c_double()
+    _lib.check(L.wl_prof_timed(C.byref(nl), C.byref(nc), C.byref(ms)))
+    _lib.check(L.wl_prof_select(-1, 0))
+    vcycles = sim.pois.n[n0:]
+
+    mlups = ncell * args.steps / elapsed / 1e6
+    avg_ms = ms.value / max(1, nl.value)
+    alg_bytes = ALG_T[dominant] * tsz * (nc.value / max(1, nl.value))
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(f"{dominant}@{m}^3/{args.dtype}")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "MLUPS (cell-updates/s) per sim_step!, 3D sphere", "value": mlups, "unit": "MLUPS",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"3D sphere {m}^3, Re=3700, {args.dtype}, uniform inflow, remeasure=false "
+                               f"(BASELINE configs[2])", "vcycles_per_solve": vcycles[:6],
+                   "mean_vcycles_per_step": float(np.sum(vcycles)) / args.steps},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": nl.value,
+                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "per_class_ms_one_step": per_class},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

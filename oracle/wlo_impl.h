@@ -137,6 +137,20 @@ T SUF(wlo_dot)(const T *a, const T *b, long n) {
     for (long q = 0; q < n; ++q) s += (double)a[q] * (double)b[q];
     return (T)s;
 }
+/* dot used by pcg!/L2: whole array (faithful, default) or inside() only (wlo_interior_reductions=1) */
+static T SUF(dot_g)(const T *a, const T *b, const wlo_grid *g) {
+    if (!wlo_interior_reductions) return SUF(wlo_dot)(a, b, g->ncell);
+    double s = 0;
+    const int k0 = g->D > 2 ? 1 : 0, k1 = g->D > 2 ? g->n[2] - 2 : 0;
+#pragma omp parallel for reduction(+ : s) schedule(static) if (g->ncell > 16384)
+    for (int k = k0; k <= k1; ++k)
+        for (int j = 1; j <= g->n[1] - 2; ++j)
+            for (int i = 1; i <= g->n[0] - 2; ++i) {
+                const long I = (long)i + g->s[1] * j + g->s[2] * k;
+                s += (double)a[I] * (double)b[I];
+            }
+    return (T)s;
+}
 static T SUF(max_all)(const T *a, long n) {
     T m = a[0];
 #pragma omp parallel for reduction(max : m) schedule(static) if (n > 16384)
@@ -333,7 +347,17 @@ double SUF(wlo_cfl)(T *sigma, const T *u, const wlo_grid *g, double nu_) {
         }
         sigma[I] = (T)s;
     });
-    const T m = SUF(max_all)(sigma, nc); /* maximum over the WHOLE array (ghosts keep stale Phi) */
+    T m = SUF(max_all)(sigma, nc); /* maximum over the WHOLE array (ghosts keep stale Phi) */
+    if (wlo_interior_reductions) {
+        m = sigma[g->s[1] + (g->D > 2 ? g->s[2] : 0) + 1];
+        const int k0 = g->D > 2 ? 1 : 0, k1 = g->D > 2 ? g->n[2] - 2 : 0;
+        for (int k = k0; k <= k1; ++k)
+            for (int j = 1; j <= g->n[1] - 2; ++j)
+                for (int i = 1; i <= g->n[0] - 2; ++i) {
+                    const T v = sigma[(long)i + g->s[1] * j + g->s[2] * k];
+                    m = v > m ? v : m;
+                }
+    }
     const T d = (T)1 / (m + (T)5 * (T)nu_);
     return (double)(d < (T)10 ? d : (T)10);
 }
@@ -414,16 +438,15 @@ void SUF(wlo_jacobi)(SUF(wlo_poisson) *p, int it) {
 /* Poisson.jl:123-143 pcg!  -- returns the number of (x,r) updates performed (diagnostic only) */
 int SUF(wlo_pcg)(SUF(wlo_poisson) *p, int it) {
     const wlo_grid *g = &p->g;
-    const long nc = g->ncell;
     T *x = p->x, *r = p->r, *e = p->eps, *z = p->z;
     int nupd = 0;
     WLO_LOOP(SUF(inside)(g), { z[I] = e[I] = r[I] * p->iD[I]; });
-    T rho = SUF(wlo_dot)(r, z, nc);
+    T rho = SUF(dot_g)(r, z, g);
     if ((rho < 0 ? -rho : rho) < (T)10 * WLO_EPS) return nupd;
     for (int i = 1; i <= it; ++i) {
         SUF(wlo_bc_per)(e, g, p->permask);
         WLO_LOOP(SUF(inside)(g), { z[I] = SUF(mult1)(p->L, p->D, e, g, I); });
-        const T alpha = rho / SUF(wlo_dot)(z, e, nc);
+        const T alpha = rho / SUF(dot_g)(z, e, g);
         const double aa = (double)(alpha < 0 ? -alpha : alpha);
         if (aa < 1e-2 || aa > 1e2) return nupd; /* NaN compares false and falls through, as in Julia */
         WLO_LOOP(SUF(inside)(g), {
@@ -433,7 +456,7 @@ int SUF(wlo_pcg)(SUF(wlo_poisson) *p, int it) {
         ++nupd;
         if (i == it) return nupd;
         WLO_LOOP(SUF(inside)(g), { z[I] = r[I] * p->iD[I]; });
-        const T rho2 = SUF(wlo_dot)(r, z, nc);
+        const T rho2 = SUF(dot_g)(r, z, g);
         if ((rho2 < 0 ? -rho2 : rho2) < (T)10 * WLO_EPS) return nupd;
         const T beta = rho2 / rho;
         WLO_LOOP(SUF(inside)(g), { e[I] = beta * e[I] + z[I]; });
@@ -443,7 +466,7 @@ int SUF(wlo_pcg)(SUF(wlo_poisson) *p, int it) {
 }
 
 /* Poisson.jl:146 */
-T SUF(wlo_L2)(const SUF(wlo_poisson) *p) { return SUF(wlo_dot)(p->r, p->r, p->g.ncell); }
+T SUF(wlo_L2)(const SUF(wlo_poisson) *p) { return SUF(dot_g)(p->r, p->r, &p->g); }
 
 /* Poisson.jl:162-172 solver!(::Poisson) */
 int SUF(wlo_solver)(SUF(wlo_poisson) *p, double tol, int itmx) {
