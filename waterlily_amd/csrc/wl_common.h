@@ -119,15 +119,24 @@ inline Range r_slice(const G &g, int i0, int j, int low0) {
 // ------------------------------------------------------------------------------------------ launch
 constexpr int WL_BX = 64;    // lanes along the fast axis = one wavefront
 constexpr int WL_BY = 4;     // rows per workgroup
-constexpr int WL_MAXB = 4096;  // grid cap (256 CUs x 16): also the max number of reduction partials
+constexpr int WL_MAXB = 4096;  // grid cap (256 CUs x 16 workgroups): also the max number of reduction partials
 
 struct Tiling {
-    int a, b, c;       // axis permutation: a = fast axis (first axis with extent > 1)
+    int a, b, c;       // axis permutation: a = fast axis (first axis with extent > 1), c = marching axis
     int na, nb, nc;    // extents along a, b, c
     int nta;           // tiles along a
-    long ntiles;       // nta * ceil(nb*nc / WL_BY)
+    int tpp;           // tiles per (a,b) plane = nta * ceil(nb / WL_BY)
+    int nchunk;        // the marching axis is cut into nchunk pieces of `clen` planes
+    int clen;
+    int nblk;          // launch grid = min(tpp, cap) * nchunk   (multiple of 8 whenever possible)
+    int ptb;           // plane tiles are strided by this many blocks (== min(tpp, cap))
     int lo[3];
 };
+// Mapping (gfx950): a workgroup owns one 64x4 tile of the (a,b) plane and MARCHES along c, so the c-1/c
+// stencil operands it needs were brought into its CU's L1/L2 by its own previous iteration; the c axis is cut
+// into chunks only to create enough workgroups (>= ~2048) to fill 256 CUs.  Hardware deals workgroups
+// round-robin over the 8 XCDs (b and b+8 share an L2), so the logical block id is un-swizzled to give every
+// XCD a CONTIGUOUS range of plane tiles: neighbouring tiles then share their halo rows through one L2.
 inline Tiling mk_tiling(const Range &R) {
     Tiling t;
     int ext[3] = {R.hi[0] - R.lo[0] + 1, R.hi[1] - R.lo[1] + 1, R.hi[2] - R.lo[2] + 1};
@@ -138,30 +147,51 @@ inline Tiling mk_tiling(const Range &R) {
     if (t.b > t.c) { int x = t.b; t.b = t.c; t.c = x; }
     t.na = ext[t.a]; t.nb = ext[t.b]; t.nc = ext[t.c];
     t.nta = (t.na + WL_BX - 1) / WL_BX;
-    long rows = (long)t.nb * t.nc;
-    t.ntiles = (long)t.nta * ((rows + WL_BY - 1) / WL_BY);
+    t.tpp = t.nta * ((t.nb + WL_BY - 1) / WL_BY);
+    t.ptb = ((t.tpp + 7) / 8) * 8;              // multiple of 8 so the XCD un-swizzle applies (idle tail blocks)
+    if (t.ptb > WL_MAXB) t.ptb = WL_MAXB;
+    int want = WL_MAXB / t.ptb;                 // chunks that keep the grid <= WL_MAXB
+    if (want < 1) want = 1;
+    if (want > t.nc) want = t.nc;
+    t.clen = (t.nc + want - 1) / want;
+    if (t.clen < 1) t.clen = 1;
+    t.nchunk = (t.nc + t.clen - 1) / t.clen;
+    t.nblk = t.ptb * t.nchunk;
     for (int d = 0; d < 3; ++d) t.lo[d] = R.lo[d];
     return t;
 }
-inline int grid_for(const Tiling &t) { return (int)(t.ntiles < WL_MAXB ? (t.ntiles < 1 ? 1 : t.ntiles) : WL_MAXB); }
+inline int grid_for(const Tiling &t) { return t.nblk; }
+
+// logical block id: XCD x (= blockIdx % 8) receives the contiguous range [x*nblk/8, (x+1)*nblk/8)
+__device__ inline int logical_block(int nblk) {
+    const int b = blockIdx.x;
+    return (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);
+}
+
+#define WL_TILE_LOOP(t, BODY)                                                              \
+    {                                                                                      \
+        const int tx__ = threadIdx.x & (WL_BX - 1), ty__ = threadIdx.x / WL_BX;            \
+        const int lb__ = logical_block(t.nblk);                                            \
+        const int ch__ = lb__ / t.ptb, p0__ = lb__ - ch__ * t.ptb;                         \
+        const int c0__ = ch__ * t.clen, c1__ = min(t.nc, c0__ + t.clen);                   \
+        for (int pt__ = p0__; pt__ < t.tpp; pt__ += t.ptb) {                               \
+            const int ta__ = pt__ % t.nta, tb__ = pt__ / t.nta;                            \
+            const int ia__ = ta__ * WL_BX + tx__, ib__ = tb__ * WL_BY + ty__;              \
+            if (ia__ < t.na && ib__ < t.nb) {                                              \
+                int idx[3];                                                                \
+                idx[t.a] = t.lo[t.a] + ia__;                                               \
+                idx[t.b] = t.lo[t.b] + ib__;                                               \
+                for (int ic__ = c0__; ic__ < c1__; ++ic__) {                               \
+                    idx[t.c] = t.lo[t.c] + ic__;                                           \
+                    BODY                                                                   \
+                }                                                                          \
+            }                                                                              \
+        }                                                                                  \
+    }
 
 template <class F>
 __global__ __launch_bounds__(WL_BX *WL_BY) void k_range(Tiling t, F f) {
-    const int tx = threadIdx.x & (WL_BX - 1), ty = threadIdx.x / WL_BX;
-    const long rows = (long)t.nb * t.nc;
-    for (long tile = blockIdx.x; tile < t.ntiles; tile += gridDim.x) {
-        const int ta = (int)(tile % t.nta);
-        const long rg = tile / t.nta;
-        const int ia = ta * WL_BX + tx;
-        const long row = rg * WL_BY + ty;
-        if (ia < t.na && row < rows) {
-            int idx[3];
-            idx[t.a] = t.lo[t.a] + ia;
-            idx[t.b] = t.lo[t.b] + (int)(row % t.nb);
-            idx[t.c] = t.lo[t.c] + (int)(row / t.nb);
-            f(idx[0], idx[1], idx[2]);
-        }
-    }
+    WL_TILE_LOOP(t, f(idx[0], idx[1], idx[2]);)
 }
 
 enum RedOp { RED_SUM = 0, RED_MAX = 1 };
@@ -200,24 +230,10 @@ __device__ inline void block_red(double (&v)[NV], int op) {
 // partials[q*gridDim.x + blockIdx.x] receives the block's reduction of acc[q].
 template <int NV, class F>
 __global__ __launch_bounds__(WL_BX *WL_BY) void k_range_red(Tiling t, F f, double *partials, int op, double init) {
-    const int tx = threadIdx.x & (WL_BX - 1), ty = threadIdx.x / WL_BX;
-    const long rows = (long)t.nb * t.nc;
     double acc[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) acc[q] = init;
-    for (long tile = blockIdx.x; tile < t.ntiles; tile += gridDim.x) {
-        const int ta = (int)(tile % t.nta);
-        const long rg = tile / t.nta;
-        const int ia = ta * WL_BX + tx;
-        const long row = rg * WL_BY + ty;
-        if (ia < t.na && row < rows) {
-            int idx[3];
-            idx[t.a] = t.lo[t.a] + ia;
-            idx[t.b] = t.lo[t.b] + (int)(row % t.nb);
-            idx[t.c] = t.lo[t.c] + (int)(row / t.nb);
-            f(idx[0], idx[1], idx[2], acc);
-        }
-    }
+    WL_TILE_LOOP(t, f(idx[0], idx[1], idx[2], acc);)
     block_red<NV>(acc, op);
     if (threadIdx.x == 0) {
 #pragma unroll
@@ -273,32 +289,35 @@ template <class T> struct Lim;
 template <> struct Lim<float> { static constexpr float eps = FLT_EPSILON; };
 template <> struct Lim<double> { static constexpr double eps = DBL_EPSILON; };
 
-// src/Flow.jl:25-34
-template <class T> __host__ __device__ inline T median3(T a, T b, T c) {
-    if (a > b) {
-        if (b >= c) return b;
-        if (a > c) return c;
-    } else {
-        if (b <= c) return b;
-        if (a < c) return c;
-    }
-    return a;
+// src/Flow.jl:25-34: the reference's branchy median(a,b,c) returns the mathematical median for every
+// non-NaN input (ties return one of the equal values), so it is evaluated branch-free: one v_med3_f32 for
+// Float32, min/max for Float64.  Only the sign of a zero result can differ from the branchy form.
+__device__ inline float median3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+__device__ inline double median3(double a, double b, double c) {
+    return fmax(fmin(a, b), fmin(fmax(a, b), c));
 }
 // src/Flow.jl:4
-template <class T> __host__ __device__ inline T quick(T u, T c, T d) {
+template <class T> __device__ inline T quick(T u, T c, T d) {
     T a1 = (((T)5 * c + (T)2 * d) - u) / (T)6;
-    T a2 = median3<T>((T)10 * c - (T)9 * u, c, d);
-    return median3<T>(a1, c, a2);
+    T a2 = median3((T)10 * c - (T)9 * u, c, d);
+    return median3(a1, c, a2);
 }
 // src/Flow.jl:3 : T add, then *0.5 in Float64
 template <class T> __device__ inline double phi(const T *f, long I, long s) { return (double)(T)(f[I] + f[I - s]) * 0.5; }
 // src/Flow.jl:6
+// (the upwind triple is selected first, then ONE quick is evaluated: same value, half the arithmetic)
 template <class T> __device__ inline double phiu(const T *f, long I, long s, double u) {
-    return u > 0 ? u * (double)quick<T>(f[I - 2 * s], f[I - s], f[I]) : u * (double)quick<T>(f[I + s], f[I], f[I - s]);
+    const bool up = u > 0;
+    const T c1 = f[I - s], c0 = f[I];
+    const T uu = up ? f[I - 2 * s] : f[I + s];
+    return u * (double)quick<T>(uu, up ? c1 : c0, up ? c0 : c1);
 }
 // src/Flow.jl:7
 template <class T> __device__ inline double phiuP(const T *f, long Ip, long I, long s, double u) {
-    return u > 0 ? u * (double)quick<T>(f[Ip], f[I - s], f[I]) : u * (double)quick<T>(f[I + s], f[I], f[I - s]);
+    const bool up = u > 0;
+    const T c1 = f[I - s], c0 = f[I];
+    const T uu = up ? f[Ip] : f[I + s];
+    return u * (double)quick<T>(uu, up ? c1 : c0, up ? c0 : c1);
 }
 // src/Flow.jl:8
 template <class T> __device__ inline double phiuL(const T *f, long I, long s, double u) {

@@ -1,0 +1,236 @@
+// wl_convdiff.h -- conv_diff! (src/Flow.jl:36-60) for D=3, non-periodic, as ONE LDS-tiled z-marching kernel.
+//
+// Layout of the work (gfx950):
+//   * a 256-thread workgroup owns a 64(x) x 4(y) column of cells and marches along z; x in [1, n0-2] so that a
+//     power-of-two grid is covered by whole 64-lane wavefronts (the two x-ghost planes go through the generic
+//     gather kernel: 0.4 % of the cells);
+//   * per z-plane the three velocity components of the tile + a 2-cell halo are staged in LDS (triple-buffered:
+//     planes k-1, k for the stencils, k+1 being filled) -- every u element is fetched from HBM/L2 once per
+//     workgroup instead of ~25x per cell; z-neighbours of the thread's own column live in a 4-deep register
+//     window; global loads for plane k+1/k+2 are issued before the flux arithmetic of plane k (latency hidden);
+//   * a thread evaluates the x and y fluxes through both faces of its cell and the z flux through the LOWER
+//     face only: the upper z flux of cell k is the lower z flux of cell k+1, computed one iteration later,
+//     so the partially summed cell is carried in registers for one iteration (15 flux evaluations per cell
+//     instead of 18);
+//   * all boundary special cases (src/Flow.jl:54-55: one-sided fluxes, Float64 accumulation on boundary faces,
+//     "top ghost included" ranges of inside_u, util.jl:55-57) are operand/flag selects: straight-line code.
+// The arithmetic per flux and the order of the six +/- updates per cell are exactly those of the reference
+// (and of the generic gather kernel in wl_ops.h), so results are bit-identical to the oracle.
+#pragma once
+#include "wl_common.h"
+
+namespace wl {
+
+constexpr int CD_BX = 64, CD_BY = 4, CD_H = 2;
+constexpr int CD_W = CD_BX + 2 * CD_H;   // 68 columns
+constexpr int CD_R = CD_BY + 2 * CD_H;   // 8 rows
+constexpr int CD_HALO = CD_W * CD_R - CD_BX * CD_BY;  // 288 halo cells per component and plane
+
+// flux through one face (src/Flow.jl:6,8,9 + the diffusive term of :45,:54,:55), returned in Float64:
+//   interior face : phiu  - nu*d      lower boundary: phiuL - nu*d      upper boundary: phiuR - nu*d
+// fm2,fm1,f0,fp1 = f[I-2s], f[I-s], f[I], f[I+s] of the transported component, uf = face velocity.
+template <class T>
+__device__ __forceinline__ double cd_flux(T fm2, T fm1, T f0, T fp1, double uf, T nu, bool lowbnd, bool topbnd) {
+    const bool neg = uf < 0;
+    const bool up = topbnd ? !neg : (uf > 0);      // phiuR takes the upwind-from-below triple unless u<0
+    const T q = quick<T>(up ? fm2 : fp1, up ? fm1 : f0, up ? f0 : fm1);
+    const double cen = (double)(T)(f0 + fm1) * 0.5;
+    const bool central = (lowbnd && uf > 0) || (topbnd && neg);
+    const double flux = uf * (central ? cen : (double)q);
+    const T nud = nu * (T)(f0 - fm1);
+    return flux - (double)nud;
+}
+template <class T> __device__ __forceinline__ T cd_add(T r, double F, bool bnd) {   // r += flux (lower face)
+    return bnd ? (T)((double)r + F) : r + (T)F;
+}
+template <class T> __device__ __forceinline__ T cd_sub(T r, double F, bool bnd) {   // r -= flux (upper face)
+    return bnd ? (T)((double)r - F) : r - (T)F;
+}
+
+template <class T, bool FUSE>
+__global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__ r, const T *__restrict__ u, T nu,
+                                                           const T *__restrict__ u0, const T *__restrict__ V, T dt,
+                                                           double a0, double a1, double a2, bool has_acc, int ntx,
+                                                           int tpp, int nblk, int clen) {
+    __shared__ T sm[3][3][CD_R][CD_W];  // [plane slot][component][row][col]
+    const int tx = threadIdx.x & (CD_BX - 1), ty = threadIdx.x / CD_BX;
+    const int b = blockIdx.x;
+    const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);  // XCD-contiguous logical id
+    const int ch = lb / tpp, pt = lb - ch * tpp;
+    const int i0 = 1 + CD_BX * (pt % ntx), j0 = CD_BY * (pt / ntx);
+    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
+    const int k0 = ch * clen, k1 = min(n2, k0 + clen);
+    if (k0 >= n2 || j0 >= n1) return;  // uniform per workgroup (padding tiles)
+    const int i = i0 + tx, j = j0 + ty;
+    const bool active = (i <= n0 - 2) && (j <= n1 - 1);
+    const int ic = min(i, n0 - 1), jc = min(j, n1 - 1);
+    const long col = (long)ic + g.s[1] * (long)jc;  // own column offset (clamped for idle threads)
+    const long sz = g.s[2], sc = g.sc;
+
+    // halo duties of this thread: halo cell h1 = t, and h2 = t + 256 when < 288
+    int hl[2] = {0, 0};
+    long hg[2] = {0, 0};
+    int nh = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int h = (int)threadIdx.x + q * 256;
+        if (h < CD_HALO) {
+            int row, cl;
+            if (h < 4 * CD_W) { const int rr = h / CD_W; row = rr < 2 ? rr : rr + CD_BY; cl = h - rr * CD_W; }
+            else { const int qq = h - 4 * CD_W; row = CD_H + (qq >> 2); const int c4 = qq & 3; cl = c4 < 2 ? c4 : c4 + CD_BX; }
+            const int gx = min(max(i0 - CD_H + cl, 0), n0 - 1), gy = min(max(j0 - CD_H + row, 0), n1 - 1);
+            hl[nh] = row * CD_W + cl;
+            hg[nh] = (long)gx + g.s[1] * (long)gy;
+            ++nh;
+        }
+    }
+    const int own_l = (ty + CD_H) * CD_W + tx + CD_H;
+    auto clampk = [n2](int k) { return min(max(k, 0), n2 - 1); };
+    auto SM = [&](int slot, int c) -> T * { return &sm[slot][c][0][0]; };
+
+    // ---- prologue: register window k0-2..k0+1 of the own column, LDS planes k0-1 and k0
+    T W[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) W[c][q] = u[col + sz * clampk(k0 - 2 + q) + sc * c];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const int kk = clampk(k0 - 1 + pl);
+        const int slot = (k0 - 1 + pl + 3) % 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            SM(slot, c)[own_l] = W[c][1 + pl];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (q < nh) SM(slot, c)[hl[q]] = u[hg[q] + sz * kk + sc * c];
+        }
+    }
+    __syncthreads();
+
+    T part[3] = {0, 0, 0};     // carried partial sums of cell k-1 (after x, y and lower-z fluxes)
+    T cu0[3] = {0, 0, 0}, cV[3] = {0, 0, 0};
+    bool carry = false;
+    const bool jlow = j >= 1;
+    const int kend = min(k1, n2 - 1);
+
+    for (int k = k0; k <= kend; ++k) {
+        const bool own = k < k1;
+        // ---- A. issue the global loads of the next planes first
+        T nxt[3], hv[2][3], e0[3], eV[3];
+        const int kn = clampk(k + 2), kh = clampk(k + 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            nxt[c] = u[col + sz * kn + sc * c];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (q < nh) hv[q][c] = u[hg[q] + sz * kh + sc * c];
+            if (FUSE) { e0[c] = u0[col + sz * k + sc * c]; eV[c] = V[col + sz * k + sc * c]; }
+        }
+        // ---- B. fluxes of plane k
+        const int s1 = (k + 3) % 3, s0 = (k + 2) % 3;  // LDS slots of planes k and k-1
+        const bool klow = k >= 1;
+        const bool lowok = jlow && klow;
+        const bool zlb = (k == 1), ztb = (k == n2 - 1);
+        T rr[3] = {0, 0, 0};
+        double Fz[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const T *P = SM(s1, c) + own_l;  // plane k, component c, centred on the own cell
+            // ---- z: lower face of cell k (also the upper face of the carried cell k-1)
+            double ufz;
+            if (c == 0) ufz = (double)(T)(W[2][2] + SM(s1, 2)[own_l - 1]) * 0.5;
+            else if (c == 1) ufz = (double)(T)(W[2][2] + SM(s1, 2)[own_l - CD_W]) * 0.5;
+            else ufz = (double)(T)(W[2][2] + W[2][1]) * 0.5;
+            Fz[c] = cd_flux<T>(W[c][0], W[c][1], W[c][2], W[c][3], ufz, nu, zlb, ztb);
+            if (own && lowok) {
+                // ---- x: lower face i, upper face i+1
+                const T xm2 = P[-2], xm1 = P[-1], x0 = W[c][2], xp1 = P[1], xp2 = P[2];
+                double ufl, ufu;
+                const T *PX = SM(s1, 0) + own_l;
+                if (c == 0) { ufl = (double)(T)(PX[0] + PX[-1]) * 0.5; ufu = (double)(T)(PX[1] + PX[0]) * 0.5; }
+                else if (c == 1) { ufl = (double)(T)(PX[0] + PX[-CD_W]) * 0.5; ufu = (double)(T)(PX[1] + PX[1 - CD_W]) * 0.5; }
+                else { ufl = (double)(T)(PX[0] + W[0][1]) * 0.5; ufu = (double)(T)(PX[1] + SM(s0, 0)[own_l + 1]) * 0.5; }
+                const bool xlb = (i == 1), xtb = (i == n0 - 2);
+                rr[c] = cd_add<T>(rr[c], cd_flux<T>(xm2, xm1, x0, xp1, ufl, nu, xlb, false), xlb);
+                rr[c] = cd_sub<T>(rr[c], cd_flux<T>(xm1, x0, xp1, xp2, ufu, nu, false, xtb), xtb);
+                // ---- y: lower face j, upper face j+1   (only rows j <= n1-2 take part, util.jl:55-57)
+                if (j <= n1 - 2) {
+                    const T ym2 = P[-2 * CD_W], ym1 = P[-CD_W], yp1 = P[CD_W], yp2 = P[2 * CD_W];
+                    const T *PY = SM(s1, 1) + own_l;
+                    double vfl, vfu;
+                    if (c == 0) { vfl = (double)(T)(PY[0] + PY[-1]) * 0.5; vfu = (double)(T)(PY[CD_W] + PY[CD_W - 1]) * 0.5; }
+                    else if (c == 1) { vfl = (double)(T)(PY[0] + PY[-CD_W]) * 0.5; vfu = (double)(T)(PY[CD_W] + PY[0]) * 0.5; }
+                    else { vfl = (double)(T)(PY[0] + W[1][1]) * 0.5; vfu = (double)(T)(PY[CD_W] + SM(s0, 1)[own_l + CD_W]) * 0.5; }
+                    const bool ylb = (j == 1), ytb = (j == n1 - 2);
+                    rr[c] = cd_add<T>(rr[c], cd_flux<T>(ym2, ym1, x0, yp1, vfl, nu, ylb, false), ylb);
+                    rr[c] = cd_sub<T>(rr[c], cd_flux<T>(ym1, x0, yp1, yp2, vfu, nu, false, ytb), ytb);
+                }
+                // ---- z lower face of the own cell (cells k <= n2-2 take part in z)
+                if (k <= n2 - 2) rr[c] = cd_add<T>(rr[c], Fz[c], zlb);
+            }
+        }
+        // ---- C. finish and store: the carried cell k-1 gets its upper z flux; cell k is stored now when it
+        //         takes no upper z flux (k == 0, k == n2-1, or j == 0), else it is carried
+        auto emit = [&](int kk, const T(&val)[3], const T(&q0)[3], const T(&qV)[3]) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                T v = val[c];
+                const long o = col + sz * kk + sc * c;
+                if (FUSE) {
+                    if (has_acc) v = (T)((double)v + (c == 0 ? a0 : (c == 1 ? a1 : a2)));
+                    r[o] = (q0[c] + dt * v) - qV[c];
+                } else {
+                    r[o] = v;
+                }
+            }
+        };
+        if (carry) {
+            T fin[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fin[c] = cd_sub<T>(part[c], Fz[c], ztb);
+            if (active) emit(k - 1, fin, cu0, cV);
+            carry = false;
+        }
+        if (own) {
+            const bool needs_up = lowok && (k <= n2 - 2);
+            if (needs_up) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { part[c] = rr[c]; cu0[c] = e0[c]; cV[c] = eV[c]; }
+                carry = true;
+            } else if (active) {
+                emit(k, rr, e0, eV);
+            }
+        }
+        // ---- D. rotate the register window, publish plane k+1 into its LDS slot
+        const int s2 = (k + 4) % 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            W[c][0] = W[c][1]; W[c][1] = W[c][2]; W[c][2] = W[c][3]; W[c][3] = nxt[c];
+            SM(s2, c)[own_l] = W[c][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (q < nh) SM(s2, c)[hl[q]] = hv[q][c];
+        }
+        __syncthreads();
+    }
+}
+
+// host side: fast kernel on x in [1, n0-2], generic gather on the two x-ghost planes
+template <class T, bool FUSE>
+int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, const T *V, double dt_, const double *acc,
+                     bool has_acc) {
+    const int ntx = (g.n[0] - 2 + CD_BX - 1) / CD_BX, nty = (g.n[1] + CD_BY - 1) / CD_BY;
+    const int tpp = ((ntx * nty + 7) / 8) * 8;  // padded to a multiple of 8 for the XCD mapping (idle tail tiles)
+    int want = WL_MAXB / tpp;
+    if (want < 1) want = 1;
+    if (want > g.n[2]) want = g.n[2];
+    const int clen = (g.n[2] + want - 1) / want;
+    const int nchunk = (g.n[2] + clen - 1) / clen;
+    const int nblk = tpp * nchunk;
+    double a3[3] = {0, 0, 0};
+    if (has_acc) for (int d = 0; d < 3; ++d) a3[d] = acc[d];
+    Prof p(WL_K_CONVDIFF, g.cells());
+    hipLaunchKernelGGL((k_convdiff3<T, FUSE>), dim3(nblk), dim3(CD_BX * CD_BY), 0, ctx().stream, g, r, u, (T)nu_, u0, V,
+                       (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen);
+    return (int)hipGetLastError();
+}
+
+}  // namespace wl

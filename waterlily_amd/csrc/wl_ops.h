@@ -7,6 +7,7 @@
 // promotions, so results match the CPU oracle to the last bit wherever no reduction is involved.
 #pragma once
 #include "wl_common.h"
+#include "wl_convdiff.h"
 
 namespace wl {
 
@@ -122,14 +123,14 @@ int op_reduce(const G &g, int kclass, int op, double init, F cell, double *parti
 // in Float64 like :54-55.  No Phi array, no 9x re-read of r, no write race.
 // FUSE: also applies accelerate! (:68-70) and the first BDIM! loop (:133): f = u0 + dt*r - V on ALL cells.
 template <class T, int D, bool FUSE>
-int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T *u0, const T *V, double dt_,
-                 const double *acc, bool has_acc) {
+int op_conv_diff_range(const G &g, const Range &R, T *r, const T *u, double nu_, int permask, const T *u0, const T *V,
+                       double dt_, const double *acc, bool has_acc) {
     const T nu = (T)nu_, dt = (T)dt_;
     double a3[3] = {0, 0, 0};
     if (has_acc) for (int d = 0; d < D; ++d) a3[d] = acc[d];
     const double a0 = a3[0], a1 = a3[1], a2 = a3[2];
     const G gg = g;
-    return launch_range(WL_K_CONVDIFF, r_whole(g), [=] __device__(int i, int j, int k) {
+    return launch_range(WL_K_CONVDIFF, R, [=] __device__(int i, int j, int k) {
         const long I = gg.at(i, j, k);
         const int idx[3] = {i, j, k};
         bool lowok = true;
@@ -194,6 +195,24 @@ _Pragma("unroll")
             }
         }
     });
+}
+
+// dispatch: D=3 non-periodic -> LDS-tiled marching kernel (wl_convdiff.h) + generic gather on the two x-ghost
+// planes; everything else (2-D, periodic directions) -> generic gather kernel over the whole array.
+template <class T, int D, bool FUSE>
+int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T *u0, const T *V, double dt_,
+                 const double *acc, bool has_acc) {
+    if constexpr (D == 3) {
+        if (permask == 0 && g.n[0] >= 5 && g.n[1] >= 5 && g.n[2] >= 5) {
+            WL_TRY((launch_convdiff3<T, FUSE>(g, r, u, nu_, u0, V, dt_, acc, has_acc)));
+            Range R0 = r_whole(g), R1 = r_whole(g);
+            R0.hi[0] = 0;
+            R1.lo[0] = g.n[0] - 1;
+            WL_TRY((op_conv_diff_range<T, D, FUSE>(g, R0, r, u, nu_, permask, u0, V, dt_, acc, has_acc)));
+            return op_conv_diff_range<T, D, FUSE>(g, R1, r, u, nu_, permask, u0, V, dt_, acc, has_acc);
+        }
+    }
+    return op_conv_diff_range<T, D, FUSE>(g, r_whole(g), r, u, nu_, permask, u0, V, dt_, acc, has_acc);
 }
 
 // accelerate!  src/Flow.jl:68-70: r[..,i] .+= g_i on every element
