@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs) into per-launch HBM
+traffic for the finest-level kernels, and update profiles/traffic.json (read by bench.py's roofline leg).
+
+Corrections, as /opt/skills/guides/MI355X_MICROARCH.md section "HBM" prescribes:
+  * FETCH_SIZE / WRITE_SIZE are in KiB;
+  * on gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read -> doubled.  Calibrated here on
+    kernels of this library whose byte counts are known exactly (pcg_direction: reads 2 arrays, writes 1;
+    pcg_init: reads 2, writes 2): corrected reads land within +4..8 % of the known counts, writes are exact.
+
+usage: parse_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <tag e.g. 512^3/f32>
+"""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+LAMBDA = {  # (operator, kernel kind, lambda ordinal) -> libwlhip kernel class
+    ("op_pcg", "k_range_red", "#1"): "pcg_init", ("op_pcg", "k_range_red", "#2"): "pcg_mult_dot",
+    ("op_pcg", "k_range_red", "#3"): "pcg_update", ("op_pcg", "k_range", "#1"): "pcg_direction",
+    ("op_increment", "k_range", "#1"): "increment", ("op_jacobi", "k_range", "#1"): "jacobi",
+    ("op_residual", "k_range_red", "#1"): "residual", ("op_bdim2", "k_range", "#1"): "bdim",
+    ("op_correct", "k_range", "#1"): "correct", ("op_div", "k_range", "#1"): "div",
+}
+
+
+def classify(name):
+    if "k_convdiff3" in name:
+        return "conv_diff"
+    m = re.search(r"(k_range_red|k_range)<.*?(op_\w+?)<", name)
+    o = re.search(r"#(\d)\}", name)
+    if not m or not o:
+        return None
+    return LAMBDA.get((m.group(2), m.group(1), "#" + o.group(1)))
+
+
+def collect(path, counter):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = classify(r["Kernel_Name"])
+        if k:
+            per[k].append(float(r["Counter_Value"]) * 1024.0)
+    out = {}
+    for k, v in per.items():
+        top = max(v)
+        fin = [x for x in v if x > 0.6 * top]  # finest-level dispatches only
+        out[k] = sum(fin) / len(fin)
+    return out
+
+
+def main():
+    fpath, wpath, tag = sys.argv[1:4]
+    rd = {k: 2.0 * v for k, v in collect(fpath, "FETCH_SIZE").items()}
+    wr = collect(wpath, "WRITE_SIZE")
+    here = os.path.dirname(os.path.abspath(__file__))
+    tfile = os.path.join(here, "traffic.json")
+    data = json.load(open(tfile)) if os.path.exists(tfile) else {}
+    for k in sorted(set(rd) | set(wr)):
+        tot = rd.get(k, 0.0) + wr.get(k, 0.0)
+        data[f"{k}@{tag}"] = tot
+        print(f"{k:14s} read(corrected) {rd.get(k, 0) / 1e9:7.3f} GB  write {wr.get(k, 0) / 1e9:7.3f} GB  total {tot / 1e9:7.3f} GB/launch")
+    json.dump(data, open(tfile, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -339,6 +339,26 @@ template <class T, int D> __device__ inline T mult1(const G &g, const T *L, cons
     return s;
 }
 
+// mult with the diagonal RECOMPUTED from the six face coefficients the stencil loads anyway
+// (D[I] = -sum_d (L[I,d]+L[I+d,d]), src/Poisson.jl:48-54: same operations as set_diag!, so the same bits as
+// the stored D as long as update! ran after the last change of L).  Saves one array read per cell.
+template <class T, int D> __device__ inline T mult1r(const G &g, const T *L, const T *x, long I) {
+    T lo[D], hi[D];
+_Pragma("unroll")
+    for (int d = 0; d < D; ++d) {
+        const T *Ld = L + (long)d * g.sc;
+        lo[d] = Ld[I];
+        hi[d] = Ld[I + g.s[d]];
+    }
+    T dg = 0;
+_Pragma("unroll")
+    for (int d = 0; d < D; ++d) dg -= (lo[d] + hi[d]);
+    T s = x[I] * dg;
+_Pragma("unroll")
+    for (int d = 0; d < D; ++d) s += x[I - g.s[d]] * lo[d] + x[I + g.s[d]] * hi[d];
+    return s;
+}
+
 // dispatch on (dtype, D)
 #define WL_DISPATCH(t, D, CALL)                                          \
     do {                                                                 \

@@ -390,7 +390,7 @@ int op_residual(const LevelT<T> &p, int permask, double *partials, State *st) {
     int np = 0;
     WL_TRY((launch_range_red<1>(WL_K_RESIDUAL, r_inside(p.g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
         const long I = q.g.at(i, j, k);
-        const T v = (q.iD[I] == 0) ? (T)0 : q.z[I] - mult1<T, D>(q.g, q.L, q.D, q.x, I);
+        const T v = (q.iD[I] == 0) ? (T)0 : q.z[I] - mult1r<T, D>(q.g, q.L, q.x, I);
         q.r[I] = v;
         acc[0] += (double)v;
     }, partials, RED_SUM, 0.0, &np)));
@@ -415,7 +415,7 @@ int op_increment(const LevelT<T> &p, int permask) {
     const LevelT<T> q = p;
     return launch_range(WL_K_INCREMENT, r_inside(p.g), [=] __device__(int i, int j, int k) {
         const long I = q.g.at(i, j, k);
-        q.r[I] = q.r[I] - mult1<T, D>(q.g, q.L, q.D, q.eps, I);
+        q.r[I] = q.r[I] - mult1r<T, D>(q.g, q.L, q.eps, I);
         q.x[I] = q.x[I] + q.eps[I];
     });
 }
@@ -462,7 +462,7 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st)
         WL_TRY((launch_range_red<1>(WL_K_PCG_MULT, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
             if (!st->active) return;
             const long I = q.g.at(i, j, k);
-            const T v = mult1<T, D>(q.g, q.L, q.D, q.eps, I);
+            const T v = mult1r<T, D>(q.g, q.L, q.eps, I);
             q.z[I] = v;
             acc[0] += (double)v * (double)q.eps[I];
         }, partials, RED_SUM, 0.0, &np)));
