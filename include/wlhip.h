@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 1
+#define WL_ABI_VERSION 2
 
 typedef enum wl_dtype { WL_F32 = 0, WL_F64 = 1 } wl_dtype;
 
@@ -39,9 +39,15 @@ enum { WL_OK = 0, WL_E_ARG = 10001, WL_E_LEVELS = 10002, WL_E_NOGPU = 10003, WL_
 /* One grid (= one multigrid level).  n[] INCLUDES the ghost layer (src/Flow.jl:112 `Ng = N .+ 2`). */
 typedef struct wl_grid {
     int32_t D;     /* 2 or 3 */
-    int32_t n[3];  /* extents incl. ghosts; n[2] = 1 when D == 2 */
+    int32_t n[3];  /* LOCAL extents incl. ghost/halo planes; n[2] = 1 when D == 2 */
     int64_t s[3];  /* element strides; s[0] must be 1 */
     int64_t sc;    /* element stride between the components of a vector field on this grid */
+    /* z-slab decomposition (multi-GPU, D == 3).  nzg == 0 means "not decomposed" (the other three are ignored).
+     * nzg  : extent along z of the UNDECOMPOSED array, ghosts included (the reference's N[3]+2);
+     * kz0  : global z index of local plane 0 (may be negative: unused padding plane below the domain);
+     * own_lo, own_hi : LOCAL plane range this rank owns (writes); planes outside are halo copies of a
+     *        neighbour's owned planes (filled by wl_halo_exchange) or unused padding. */
+    int32_t nzg, kz0, own_lo, own_hi;
 } wl_grid;
 
 /* ------------------------------------------------------------------ runtime */
@@ -57,6 +63,29 @@ int wl_free(void *p);
 int wl_h2d(void *dst, const void *src, size_t bytes);
 int wl_d2h(void *dst, const void *src, size_t bytes);
 int wl_memset0(void *p, size_t bytes);
+
+/* ------------------------------------------------------------------ multi-GPU communicator (one per process)
+ * z-slab decomposition, one process per GPU.  Production: RCCL over xGMI -- rank 0 calls
+ * wl_comm_unique_id, the host broadcasts the 128 bytes (torch.distributed / MPI / files), every rank calls
+ * wl_comm_init_rccl.  Testing: wl_comm_init_host routes every collective through host callbacks (device
+ * buffers are staged through pinned memory), so any transport (torch.distributed gloo) can carry it. */
+int wl_comm_unique_id(void *out128);
+int wl_comm_init_rccl(const void *id128, int rank, int nranks);
+/* sendrecv: exchange `bytes` with both z-neighbours (host pointers; NULL where there is no neighbour).
+ * allreduce: in-place on n doubles, op 0 = sum, 1 = max.  allgather: every rank contributes `bytes` at
+ * offset rank*bytes of `buf`. */
+typedef int (*wl_host_sendrecv_fn)(void *user, const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi,
+                                   int64_t bytes);
+typedef int (*wl_host_allreduce_fn)(void *user, double *vals, int n, int op);
+typedef int (*wl_host_allgather_fn)(void *user, void *buf, int64_t bytes);
+int wl_comm_init_host(int rank, int nranks, wl_host_sendrecv_fn sr, wl_host_allreduce_fn ar, wl_host_allgather_fn ag,
+                      void *user);
+int wl_comm_finalize(void);
+int wl_comm_rank(int *rank, int *nranks);
+/* fill the halo planes of a (vector) field from the z-neighbours: `depth` planes each side, `ncomp` components */
+int wl_halo_exchange(wl_dtype t, const wl_grid *g, void *a, int ncomp, int depth);
+/* all-reduce n host doubles over the ranks (op 0 = sum, 1 = max); identity when there is no communicator */
+int wl_allreduce(double *vals_host, int n, int op);
 
 /* ------------------------------------------------------------------ util.jl operators */
 /* BC!(a,A,saveexit,perdir)            src/util.jl:192-210 */

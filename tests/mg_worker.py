@@ -1,0 +1,65 @@
+"""Worker for tests/test_multi_gpu.py: launched with torch.distributed.run, N ranks sharing ONE GPU.
+
+Every rank builds (a) the undecomposed simulation and (b) its z-slab of the decomposed one, steps both and
+compares the gathered slab fields with the undecomposed ones.  Transport: torch.distributed gloo through the
+host-callback communicator (the RCCL communicator needs one GPU per rank; the C++ code above the transport
+-- slab kernels, halo exchange placement, all-reduces, replicated coarse levels -- is identical)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from waterlily_amd import dist as wd  # noqa: E402
+from waterlily_amd import sim as S  # noqa: E402
+from waterlily_amd.body import AutoBody, norm2  # noqa: E402
+
+
+def main():
+    case = sys.argv[1] if len(sys.argv) > 1 else "sphere_f32"
+    dist.init_process_group("gloo")
+    rank, size = dist.get_rank(), dist.get_world_size()
+    wd.init_host()
+    T = np.float64 if case.endswith("f64") else np.float32
+    m = 32
+    dims = (m, m, m) if "long" not in case else (m, m, 2 * m)
+    R, c = m / 8, m / 2 - 1
+    if case.startswith("donut"):
+        Rm, rm, cc = m / 4, m / 16, m / 2
+
+        def sdf(x, t):
+            q = torch.sqrt((x[1] - cc) ** 2 + (x[2] - cc) ** 2) - Rm
+            return torch.sqrt((x[0] - cc) ** 2 + q ** 2) - rm
+        body, L, nu = AutoBody(sdf), Rm, Rm / 1000
+    else:
+        body, L, nu = AutoBody(lambda x, t: norm2(x - c) - R), 2 * R, 2 * R / 3700
+    kw = dict(nu=nu, body=body, T=T, exitBC=("exit" in case))
+    ref = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=None, **kw)
+    slab = wd.Slab(rank, size, dims[2])
+    sim = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=slab, **kw)
+    out = {"rank": rank, "levels": [(tuple(l.layout.Ng), l.layout.slab is not None) for l in sim.pois.levels]}
+    # static fields after construction
+    for k in ("u", "mu0", "mu1", "V"):
+        out["init_" + k] = float(np.max(np.abs(S.gather(getattr(sim.flow, k)) - S.to_host(getattr(ref.flow, k)))))
+    nsteps = 3
+    for _ in range(nsteps):
+        S.sim_step(ref, remeasure=False)
+        S.sim_step(sim, remeasure=False)
+    out["n_ref"], out["n_slab"] = ref.pois.n, sim.pois.n
+    out["dt_ref"], out["dt_slab"] = ref.flow.dt, sim.flow.dt
+    for k in ("u", "p", "f"):
+        a, b = S.gather(getattr(sim.flow, k)), S.to_host(getattr(ref.flow, k))
+        out["d_" + k] = float(np.max(np.abs(a - b)) / max(1e-30, np.max(np.abs(b))))
+    out["force_ref"] = S.pressure_force(ref).tolist()
+    out["force_slab"] = S.pressure_force(sim).tolist()
+    wd.finalize()
+    if rank == 0:
+        print("RESULT " + json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

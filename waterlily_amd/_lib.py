@@ -23,7 +23,8 @@ class WlError(RuntimeError):
 
 
 class Grid(C.Structure):
-    _fields_ = [("D", C.c_int32), ("n", C.c_int32 * 3), ("s", C.c_int64 * 3), ("sc", C.c_int64)]
+    _fields_ = [("D", C.c_int32), ("n", C.c_int32 * 3), ("s", C.c_int64 * 3), ("sc", C.c_int64),
+                ("nzg", C.c_int32), ("kz0", C.c_int32), ("own_lo", C.c_int32), ("own_hi", C.c_int32)]
 
 
 class LevelDesc(C.Structure):
@@ -33,6 +34,11 @@ class LevelDesc(C.Structure):
 class FlowDesc(C.Structure):
     _fields_ = [("g", Grid)] + [(k, C.c_void_p) for k in ("u", "u0", "f", "p", "sigma", "V", "mu0", "mu1")] + [
         ("nu", C.c_double), ("exitBC", C.c_int32), ("perdir_mask", C.c_int32)]
+
+
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 
 
 def build(force: bool = False) -> str:
@@ -76,6 +82,13 @@ def lib() -> C.CDLL:
         "wl_h2d": (i, [vp, vp, C.c_size_t]),
         "wl_d2h": (i, [vp, vp, C.c_size_t]),
         "wl_memset0": (i, [vp, C.c_size_t]),
+        "wl_comm_unique_id": (i, [vp]),
+        "wl_comm_init_rccl": (i, [vp, i, i]),
+        "wl_comm_init_host": (i, [i, i, SENDRECV_FN, ALLREDUCE_FN, ALLGATHER_FN, vp]),
+        "wl_comm_finalize": (i, []),
+        "wl_comm_rank": (i, [ip, ip]),
+        "wl_halo_exchange": (i, [i, gp, vp, i, i]),
+        "wl_allreduce": (i, [dp, i, i]),
         "wl_bc_vec": (i, [i, gp, vp, dp, i, i]),
         "wl_bc_per": (i, [i, gp, vp, i]),
         "wl_exit_bc": (i, [i, gp, vp, vp, dp, d]),
@@ -119,7 +132,7 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.wl_abi_version() != 1:
+    if L.wl_abi_version() != 2:
         raise WlError("libwlhip.so ABI version mismatch; rebuild it")
     _lib = L
     return L

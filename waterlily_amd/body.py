@@ -157,31 +157,36 @@ def _centres(Ng: Sequence[int], lo: int, hi: int) -> np.ndarray:
 
 
 def measure_fields(body, dims: Sequence[int], t: float = 0.0, eps: float = 1.0, T=np.float32,
-                   chunk_cells: int = 1 << 22):
+                   chunk_cells: int = 1 << 22, slab=None):
     """Body.jl:31-50 before the two BC! calls: returns host arrays (mu0, mu1, V, d), Fortran order,
     shaped (Ng...,D), (Ng...,D,D), (Ng...,D), (Ng...).  `d` holds sdf at the cell centres (the
     reference stores it in flow.sigma).  Cells outside `inside(p)` keep mu0=1, mu1=V=0."""
     D = len(dims)
-    Ng = tuple(int(n) + 2 for n in dims)
+    Ng = tuple(int(n) + 2 for n in dims)      # extents of the undecomposed array
     T = np.dtype(T)
-    m0 = np.ones(Ng + (D,), dtype=T, order="F")
-    m1 = np.zeros(Ng + (D, D), dtype=T, order="F")
-    Vv = np.zeros(Ng + (D,), dtype=T, order="F")
-    dd = np.zeros(Ng, dtype=T, order="F")
+    # z-slab (waterlily_amd.dist.Slab): local arrays hold the global planes kz0 .. kz0+n2l-1, halos included --
+    # they are evaluated directly from the sdf, so no exchange is needed for the coefficient fields
+    kz0 = slab.kz0 if slab is not None else 0
+    Nl = Ng if slab is None else Ng[:-1] + (slab.n2l,)
+    m0 = np.ones(Nl + (D,), dtype=T, order="F")
+    m1 = np.zeros(Nl + (D, D), dtype=T, order="F")
+    Vv = np.zeros(Nl + (D,), dtype=T, order="F")
+    dd = np.zeros(Nl, dtype=T, order="F")
     if body is None or isinstance(body, NoBody):
         return m0, m1, Vv, dd
     d2 = T.type((2 + eps) ** 2)
     plane = int(np.prod(Ng[:-1]))
     step = max(1, chunk_cells // plane)
-    for lo in range(1, Ng[-1] - 1, step):
-        hi = min(Ng[-1] - 1, lo + step)
+    g_lo, g_hi = max(1, kz0), min(Ng[-1] - 1, kz0 + Nl[-1])   # global interior planes present locally
+    for lo in range(g_lo, g_hi, step):
+        hi = min(g_hi, lo + step)
         xc = _centres(Ng, lo, hi)
         inner = tuple(slice(1, n - 1) for n in Ng[:-1]) + (slice(None),)
         xc = xc[(slice(None),) + inner]                     # interior cells of this chunk
         shp = xc.shape[1:]
         pts = torch.from_numpy(np.ascontiguousarray(xc.reshape(D, -1)))
         dc = sdf(body, pts, t).numpy().astype(T)             # stored into sigma::T (Body.jl:34)
-        sel = inner[:-1] + (slice(lo, hi),)
+        sel = inner[:-1] + (slice(lo - kz0, hi - kz0),)
         dd[sel] = dc.reshape(shp)
         band = (dc * dc) < d2                                 # Body.jl:35, compared in T
         inside_body = (~band) & (dc < 0)
@@ -194,7 +199,7 @@ def measure_fields(body, dims: Sequence[int], t: float = 0.0, eps: float = 1.0, 
             bidx = np.nonzero(band)[0]
             xb = np.ascontiguousarray(xc.reshape(D, -1)[:, bidx])
             sub = np.unravel_index(bidx, shp)
-            full = tuple(s + 1 for s in sub[:-1]) + (sub[-1] + lo,)
+            full = tuple(s + 1 for s in sub[:-1]) + (sub[-1] + lo - kz0,)
             for i in range(D):
                 xf = xb.copy()
                 xf[i] -= 0.5                                  # face location loc(i,I) (util.jl:160)
@@ -208,7 +213,7 @@ def measure_fields(body, dims: Sequence[int], t: float = 0.0, eps: float = 1.0, 
     return m0, m1, Vv, dd
 
 
-def nds_band(body, dims: Sequence[int], t: float = 0.0, chunk_cells: int = 1 << 22):
+def nds_band(body, dims: Sequence[int], t: float = 0.0, chunk_cells: int = 1 << 22, slab=None):
     """Metrics.jl:84-87 evaluated over inside(p): returns (idx, nds) where idx are the column-major
     linear indices (ghost-inclusive extents) of cells with a non-zero n*kern(clamp(d,-1,1)) and nds is
     the (nband, D) Float64 array of those vectors (positions and normals in Float64, Metrics.jl:96)."""
@@ -220,8 +225,12 @@ def nds_band(body, dims: Sequence[int], t: float = 0.0, chunk_cells: int = 1 << 
     plane = int(np.prod(Ng[:-1]))
     step = max(1, chunk_cells // plane)
     idxs, vals = [], []
-    for lo in range(1, Ng[-1] - 1, step):
-        hi = min(Ng[-1] - 1, lo + step)
+    # z-slab: only the interior planes this rank OWNS (the force is all-reduced); indices are local
+    kz0 = slab.kz0 if slab is not None else 0
+    g_lo = 1 if slab is None else max(1, slab.kz0 + slab.own_lo)
+    g_hi = Ng[-1] - 1 if slab is None else min(Ng[-1] - 1, slab.kz0 + slab.own_hi + 1)
+    for lo in range(g_lo, g_hi, step):
+        hi = min(g_hi, lo + step)
         xc = _centres(Ng, lo, hi)
         inner = tuple(slice(1, n - 1) for n in Ng[:-1]) + (slice(None),)
         xc = xc[(slice(None),) + inner]
@@ -236,7 +245,7 @@ def nds_band(body, dims: Sequence[int], t: float = 0.0, chunk_cells: int = 1 << 
         v = (n * kern(np.clip(d, -1, 1))[None]).T           # (m, D)
         keep = np.any(v != 0, axis=1)
         sub = np.unravel_index(near[keep], shp)
-        full = [s + 1 for s in sub[:-1]] + [sub[-1] + lo]
+        full = [s + 1 for s in sub[:-1]] + [sub[-1] + lo - kz0]
         lin = sum(f.astype(np.int64) * int(s) for f, s in zip(full, strides))
         idxs.append(lin)
         vals.append(v[keep])

@@ -2,9 +2,83 @@
 #include <cstdarg>
 #include <cstring>
 
+#include <rccl/rccl.h>
+
 #include "wl_ops.h"
 
 namespace wl {
+
+// ------------------------------------------------------------------------------------------ communicators
+// RCCL over xGMI: neighbour send/recv pairs and world collectives, enqueued on the compute stream (so they are
+// ordered with the kernels that produce/consume the planes without host synchronisation).
+struct RcclComm : Comm {
+    ncclComm_t nc = nullptr;
+    ~RcclComm() override { if (nc) ncclCommDestroy(nc); }
+    int chk(ncclResult_t r, const char *what) {
+        if (r == ncclSuccess) return 0;
+        ctx().err = std::string("rccl: ") + what + ": " + ncclGetErrorString(r);
+        return WL_E_STATE;
+    }
+    int allreduce(double *dev, int n, int op) override {
+        return chk(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, nc, ctx().stream), "allreduce");
+    }
+    int sendrecv(const void *slo, void *rlo, const void *shi, void *rhi, size_t bytes) override {
+        int rc = chk(ncclGroupStart(), "groupStart");
+        if (rc) return rc;
+        if (slo) { ncclSend(slo, bytes, ncclChar, rank - 1, nc, ctx().stream); ncclRecv(rlo, bytes, ncclChar, rank - 1, nc, ctx().stream); }
+        if (shi) { ncclSend(shi, bytes, ncclChar, rank + 1, nc, ctx().stream); ncclRecv(rhi, bytes, ncclChar, rank + 1, nc, ctx().stream); }
+        return chk(ncclGroupEnd(), "groupEnd(sendrecv)");
+    }
+    int allgather(void *buf, size_t bytes) override {
+        return chk(ncclAllGather((const char *)buf + (size_t)rank * bytes, buf, bytes, ncclChar, nc, ctx().stream), "allgather");
+    }
+};
+
+// Host-callback twin (tests: 2+ ranks sharing one GPU, transport = torch.distributed gloo).  Every operation
+// synchronises the stream and stages through pinned host memory: correct, not fast.
+struct HostComm : Comm {
+    wl_host_sendrecv_fn sr; wl_host_allreduce_fn ar; wl_host_allgather_fn ag; void *user;
+    char *pin = nullptr; size_t cap = 0;
+    ~HostComm() override { if (pin) (void)hipHostFree(pin); }
+    int need(size_t b) {
+        if (b <= cap) return 0;
+        if (pin) (void)hipHostFree(pin);
+        cap = b * 2;
+        return (int)hipHostMalloc((void **)&pin, cap, hipHostMallocDefault);
+    }
+    int allreduce(double *dev, int n, int op) override {
+        double v[8];
+        WL_HIP(hipMemcpyAsync(v, dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx().stream));
+        WL_HIP(hipStreamSynchronize(ctx().stream));
+        if (ar(user, v, n, op)) return fail(WL_E_STATE, "host allreduce callback failed", __FILE__, __LINE__);
+        WL_HIP(hipMemcpyAsync(dev, v, sizeof(double) * n, hipMemcpyHostToDevice, ctx().stream));
+        WL_HIP(hipStreamSynchronize(ctx().stream));
+        return 0;
+    }
+    int sendrecv(const void *slo, void *rlo, const void *shi, void *rhi, size_t bytes) override {
+        WL_TRY(need(4 * bytes));
+        char *hs_lo = pin, *hr_lo = pin + bytes, *hs_hi = pin + 2 * bytes, *hr_hi = pin + 3 * bytes;
+        if (slo) WL_HIP(hipMemcpyAsync(hs_lo, slo, bytes, hipMemcpyDeviceToHost, ctx().stream));
+        if (shi) WL_HIP(hipMemcpyAsync(hs_hi, shi, bytes, hipMemcpyDeviceToHost, ctx().stream));
+        WL_HIP(hipStreamSynchronize(ctx().stream));
+        if (sr(user, slo ? hs_lo : nullptr, slo ? hr_lo : nullptr, shi ? hs_hi : nullptr, shi ? hr_hi : nullptr, (int64_t)bytes))
+            return fail(WL_E_STATE, "host sendrecv callback failed", __FILE__, __LINE__);
+        if (rlo) WL_HIP(hipMemcpyAsync(rlo, hr_lo, bytes, hipMemcpyHostToDevice, ctx().stream));
+        if (rhi) WL_HIP(hipMemcpyAsync(rhi, hr_hi, bytes, hipMemcpyHostToDevice, ctx().stream));
+        WL_HIP(hipStreamSynchronize(ctx().stream));
+        return 0;
+    }
+    int allgather(void *buf, size_t bytes) override {
+        const size_t tot = bytes * (size_t)size;
+        WL_TRY(need(tot));
+        WL_HIP(hipMemcpyAsync(pin + (size_t)rank * bytes, (char *)buf + (size_t)rank * bytes, bytes, hipMemcpyDeviceToHost, ctx().stream));
+        WL_HIP(hipStreamSynchronize(ctx().stream));
+        if (ag(user, pin, (int64_t)bytes)) return fail(WL_E_STATE, "host allgather callback failed", __FILE__, __LINE__);
+        WL_HIP(hipMemcpyAsync(buf, pin, tot, hipMemcpyHostToDevice, ctx().stream));
+        WL_HIP(hipStreamSynchronize(ctx().stream));
+        return 0;
+    }
+};
 
 Ctx &ctx() {
     static Ctx c;
@@ -53,6 +127,12 @@ int check_grid(const wl_grid *g) {
     if (g->D == 3 && g->s[2] < g->s[1] * g->n[1]) return fail(WL_E_ARG, "grid.s[2] < s[1]*n[1]", __FILE__, __LINE__);
     const int64_t sp = g->D == 3 ? g->s[2] * g->n[2] : g->s[1] * g->n[1];
     if (g->sc < sp) return fail(WL_E_ARG, "grid.sc smaller than one component", __FILE__, __LINE__);
+    if (g->D == 3 && g->nzg > 0) {
+        if (g->own_lo < 0 || g->own_hi >= g->n[2] || g->own_lo > g->own_hi)
+            return fail(WL_E_ARG, "grid.own_lo/own_hi outside the local planes", __FILE__, __LINE__);
+        if (g->kz0 + g->own_lo < 0 || g->kz0 + g->own_hi > g->nzg - 1)
+            return fail(WL_E_ARG, "owned planes outside the global array", __FILE__, __LINE__);
+    }
     return 0;
 }
 
@@ -126,6 +206,7 @@ template <class T, int D> static int mg_update(wl_mg *m) {
     for (int l = 1; l < m->nlev; ++l) {
         LevelT<T> a = lvl<T>(m, l), b = lvl<T>(m, l - 1);
         WL_TRY((op_restrictL<T, D>(a.g, a.L, b.g, b.L, m->permask)));
+        WL_TRY((coarse_L_finish<T, D>(a.g, a.L, b.g, m->permask)));
         WL_TRY((op_set_diag<T, D>(a.g, a.D, a.iD, a.L)));
     }
     return 0;
@@ -136,6 +217,11 @@ template <class T, int D> static int mg_vcycle(wl_mg *m, int l) {
     LevelT<T> fine = lvl<T>(m, l), coarse = lvl<T>(m, l + 1);
     WL_TRY((op_jacobi<T, D>(fine, 1, m->permask)));
     WL_TRY((op_restrict<T, D>(coarse.g, coarse.r, fine.g, fine.r)));
+    if (ctx().comm && ctx().comm->size > 1 && fine.g.dist && !coarse.g.dist) {
+        // hand-over to the replicated coarse levels: every rank restricted the children it owns
+        const int nzl = (fine.g.nzg - 2) / ctx().comm->size / 2;
+        WL_TRY(ctx().comm->allgather(coarse.r + coarse.g.s[2], (size_t)nzl * coarse.g.s[2] * sizeof(T)));
+    }
     {
         Prof p(WL_K_MISC, coarse.g.cells());
         WL_HIP(hipMemsetAsync(coarse.x, 0, (size_t)span(coarse.g) * sizeof(T), ctx().stream));
@@ -191,18 +277,25 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
         WL_HIP(hipMemcpyAsync(u0, u, vbytes, hipMemcpyDeviceToDevice, ctx().stream));
     }
     // predictor (:157-161): conv_diff! + accelerate! + BDIM! #1 fused, then BDIM! #2
+    // (z-slab runs: u carries a 2-plane halo for QUICK, f a 1-plane halo for mu_ddn; exchanges are no-ops otherwise)
     WL_TRY((op_conv_diff<T, D, true>(g, f, u0, d.nu, d.perdir_mask, u0, V, dt, gp, gp != nullptr)));
+    WL_TRY((halo_exchange<T>(g, f, D, 1)));
     WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, u, u0, U, dt, a->sc.partials, a->sc.st)));
+    WL_TRY((halo_exchange<T>(g, u, D, 1)));
     WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0])));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
+    WL_TRY((halo_exchange<T>(g, u, D, 2)));
     // corrector (:164-167)
     WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr)));
+    WL_TRY((halo_exchange<T>(g, f, D, 1)));
     WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
+    WL_TRY((halo_exchange<T>(g, u, D, 1)));
     WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1])));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
+    WL_TRY((halo_exchange<T>(g, u, D, 2)));
     // push!(a.dt, CFL(a)) (:168)
     WL_TRY((op_cfl<T, D>(g, (T *)d.sigma, u, d.nu, a->sc.partials, a->sc.st)));
     WL_TRY(a->sc.fetch());
@@ -241,8 +334,71 @@ __global__ __launch_bounds__(256) void k_pforce(const T *p, const int64_t *idx, 
     if (threadIdx.x == 0)
         for (int c = 0; c < 3; ++c) partials[(long)c * gridDim.x + blockIdx.x] = acc[c];
 }
+template <class T, int D> static int restrictL_full(const G &A, T *a, const G &B, const T *b, int permask) {
+    WL_TRY((op_restrictL<T, D>(A, a, B, b, permask)));
+    return coarse_L_finish<T, D>(A, a, B, permask);
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
+
+// ---- communicator
+int wl_comm_unique_id(void *out128) {
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(WL_E_STATE, ncclGetErrorString(r), __FILE__, __LINE__);
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    memcpy(out128, &id, 128);
+    return 0;
+}
+int wl_comm_init_rccl(const void *id128, int rank, int nranks) {
+    if (ctx().comm) return fail(WL_E_STATE, "communicator already initialised", __FILE__, __LINE__);
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    RcclComm *c = new RcclComm();
+    c->rank = rank; c->size = nranks;
+    ncclResult_t r = ncclCommInitRank(&c->nc, nranks, id, rank);
+    if (r != ncclSuccess) { delete c; return fail(WL_E_STATE, ncclGetErrorString(r), __FILE__, __LINE__); }
+    ctx().comm = c;
+    return 0;
+}
+int wl_comm_init_host(int rank, int nranks, wl_host_sendrecv_fn sr, wl_host_allreduce_fn ar, wl_host_allgather_fn ag,
+                      void *user) {
+    if (ctx().comm) return fail(WL_E_STATE, "communicator already initialised", __FILE__, __LINE__);
+    if (!sr || !ar || !ag) return fail(WL_E_ARG, "null callback", __FILE__, __LINE__);
+    HostComm *c = new HostComm();
+    c->rank = rank; c->size = nranks; c->sr = sr; c->ar = ar; c->ag = ag; c->user = user;
+    ctx().comm = c;
+    return 0;
+}
+int wl_comm_finalize(void) {
+    if (ctx().comm) { (void)hipStreamSynchronize(ctx().stream); delete ctx().comm; ctx().comm = nullptr; }
+    return 0;
+}
+int wl_comm_rank(int *rank, int *nranks) {
+    *rank = ctx().comm ? ctx().comm->rank : 0;
+    *nranks = ctx().comm ? ctx().comm->size : 1;
+    return 0;
+}
+int wl_halo_exchange(wl_dtype t, const wl_grid *g, void *a, int ncomp, int depth) {
+    WL_TRY(check_grid(g));
+    const G gg = mkG(g);
+    if (t == WL_F32) return halo_exchange<float>(gg, (float *)a, ncomp, depth);
+    return halo_exchange<double>(gg, (double *)a, ncomp, depth);
+}
+int wl_allreduce(double *vals, int n, int op) {
+    Comm *cm = ctx().comm;
+    if (!cm || cm->size == 1) return 0;
+    if (n > 4) return fail(WL_E_ARG, "wl_allreduce: n <= 4", __FILE__, __LINE__);
+    int rc = 0;
+    Scratch &S = global_scratch(&rc);
+    WL_TRY(rc);
+    WL_HIP(hipMemcpyAsync(S.st->red, vals, sizeof(double) * n, hipMemcpyHostToDevice, ctx().stream));
+    WL_TRY(cm->allreduce(S.st->red, n, op));
+    WL_HIP(hipMemcpyAsync(vals, S.st->red, sizeof(double) * n, hipMemcpyDeviceToHost, ctx().stream));
+    WL_HIP(hipStreamSynchronize(ctx().stream));
+    return 0;
+}
 
 int wl_abi_version(void) { return WL_ABI_VERSION; }
 const char *wl_last_error(void) { return ctx().err.c_str(); }
@@ -352,7 +508,7 @@ int wl_restrictL(wl_dtype t, const wl_grid *ga, void *a, const wl_grid *gb, cons
     WL_TRY(check_grid(ga));
     WL_TRY(check_grid(gb));
     const G A = mkG(ga), B = mkG(gb);
-    WL_DISPATCH(t, ga->D, (op_restrictL<T, DD>(A, (T *)a, B, (const T *)b, perdir_mask)));
+    WL_DISPATCH(t, ga->D, (restrictL_full<T, DD>(A, (T *)a, B, (const T *)b, perdir_mask)));
 }
 int wl_restrict(wl_dtype t, const wl_grid *ga, void *a, const wl_grid *gb, const void *b) {
     WL_TRY(check_grid(ga));
@@ -377,9 +533,11 @@ int wl_mg_create(wl_mg **out, wl_dtype t, int nlevels, const wl_level_desc *leve
         if (!d.L || !d.D || !d.iD || !d.x || !d.eps || !d.r || !d.z)
             return fail(WL_E_ARG, "wl_mg_create: null level array", __FILE__, __LINE__);
         if (l > 0)
-            for (int k = 0; k < d.g.D; ++k)
-                if (d.g.n[k] != 1 + levels[l - 1].g.n[k] / 2)  // restrictML, src/MultiLevelPoisson.jl:20
+            for (int k = 0; k < d.g.D; ++k) {
+                auto gext = [k](const wl_grid &g) { return (k == 2 && g.nzg > 0) ? g.nzg : g.n[k]; };
+                if (gext(d.g) != 1 + gext(levels[l - 1].g) / 2)  // restrictML, src/MultiLevelPoisson.jl:20
                     return fail(WL_E_ARG, "wl_mg_create: level extents must be 1+N/2 of the finer level", __FILE__, __LINE__);
+            }
     }
     wl_mg *m = new wl_mg();
     m->t = t; m->D = levels[0].g.D; m->nlev = nlevels; m->permask = perdir_mask;
@@ -494,10 +652,10 @@ int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx, c
     WL_GS();
     (void)gg;
     out[0] = out[1] = out[2] = 0;
-    if (nband <= 0) return 0;
     int nb = (int)((nband + 255) / 256);
     if (nb > 1024) nb = 1024;
-    {
+    if (nband <= 0) nb = 0;   // a rank whose slab holds no part of the body still joins the all-reduce
+    if (nb > 0) {
         Prof pr(WL_K_PFORCE, nband);
         if (t == WL_F32)
             hipLaunchKernelGGL(k_pforce<float>, dim3(nb), dim3(256), 0, ctx().stream, (const float *)p, idx, nds, nband, g->D, S.partials);
@@ -506,7 +664,7 @@ int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx, c
         WL_HIP(hipGetLastError());
     }
     State *st = S.st;
-    WL_TRY((launch_finalize<3>(S.partials, nb, RED_SUM, 0.0, [=] __device__(double(&v)[3]) {
+    WL_TRY((launch_finalize<3>(gg.dist, S.partials, nb, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
         st->out[0] = v[0]; st->out[1] = v[1]; st->out[2] = v[2]; })));
     WL_TRY(S.fetch());
     for (int c = 0; c < g->D; ++c) out[c] = S.hst->out[c];

@@ -25,7 +25,18 @@ namespace wl {
 // ------------------------------------------------------------------------------------------ context
 struct TimedEvt { hipEvent_t a, b; int64_t cells; };
 
+// One communicator per process (z-slab neighbours + world collectives).  All buffers are DEVICE pointers and all
+// operations are enqueued on ctx().stream (RCCL) or staged through pinned host memory (host-callback twin).
+struct Comm {
+    int rank = 0, size = 1;
+    virtual ~Comm() {}
+    virtual int allreduce(double *dev, int n, int op) = 0;                       // op: 0 sum, 1 max; in place
+    virtual int sendrecv(const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi, size_t bytes) = 0;
+    virtual int allgather(void *buf, size_t bytes_per_rank) = 0;                  // in place, rank r at r*bytes
+};
+
 struct Ctx {
+    Comm *comm = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
     int64_t launches[WL_K_COUNT] = {0};
@@ -68,11 +79,16 @@ struct G {  // device-side copy of wl_grid (+ derived values)
     int n[3];
     long s[3];
     long sc;
+    int nzg;           // global z extent incl. ghosts (== n[2] when not decomposed)
+    int kz0;           // global z index of local plane 0
+    int zlo, zhi;      // owned local planes (inclusive)
+    bool dist;         // z-slab of a decomposed array
+    __host__ __device__ int kg(int k) const { return k + kz0; }
     __host__ __device__ long at(int i, int j, int k) const { return (long)i + s[1] * (long)j + s[2] * (long)k; }
     long cells() const { return (long)n[0] * n[1] * n[2]; }
-    long interior_cells() const {
+    long interior_cells() const {  // of the UNDECOMPOSED array (src/Poisson.jl:94 length(inside(r)))
         long c = 1;
-        for (int d = 0; d < D; ++d) c *= (long)(n[d] - 2);
+        for (int d = 0; d < D; ++d) c *= (long)((d == 2 ? nzg : n[d]) - 2);
         return c;
     }
 };
@@ -81,6 +97,8 @@ inline G mkG(const wl_grid *g) {
     o.D = g->D;
     for (int d = 0; d < 3; ++d) { o.n[d] = g->n[d]; o.s[d] = g->s[d]; }
     o.sc = g->sc;
+    if (g->D == 3 && g->nzg > 0) { o.nzg = g->nzg; o.kz0 = g->kz0; o.zlo = g->own_lo; o.zhi = g->own_hi; o.dist = true; }
+    else { o.nzg = g->n[2]; o.kz0 = 0; o.zlo = 0; o.zhi = g->n[2] - 1; o.dist = false; }
     return o;
 }
 int check_grid(const wl_grid *g);
@@ -89,29 +107,46 @@ struct Range {
     int lo[3], hi[3];
     long count() const {
         long c = 1;
-        for (int d = 0; d < 3; ++d) c *= (long)(hi[d] - lo[d] + 1);
+        for (int d = 0; d < 3; ++d) {
+            if (hi[d] < lo[d]) return 0;
+            c *= (long)(hi[d] - lo[d] + 1);
+        }
         return c;
     }
 };
+// z extents of every range are expressed in GLOBAL plane numbers and clipped to the planes this rank owns
+inline void clip_z(const G &g, Range &r, int glo, int ghi) {
+    if (g.D < 3) { r.lo[2] = r.hi[2] = 0; return; }
+    const int lo = glo - g.kz0, hi = ghi - g.kz0;
+    r.lo[2] = lo > g.zlo ? lo : g.zlo;
+    r.hi[2] = hi < g.zhi ? hi : g.zhi;   // may come out empty (hi < lo): launch_range skips it
+}
 inline Range r_inside(const G &g) {  // src/util.jl:47
     Range r;
     for (int d = 0; d < 3; ++d) {
         if (d < g.D) { r.lo[d] = 1; r.hi[d] = g.n[d] - 2; } else { r.lo[d] = r.hi[d] = 0; }
     }
+    clip_z(g, r, 1, g.nzg - 2);
     return r;
 }
 inline Range r_whole(const G &g) {
     Range r;
     for (int d = 0; d < 3; ++d) { r.lo[d] = 0; r.hi[d] = g.n[d] - 1; }
+    clip_z(g, r, 0, g.nzg - 1);
     return r;
 }
 // src/util.jl:180-182 slice(dims,i,j,low) with 0-based plane index `i0` and lower bound `low0`
+// (i0 and low0 are GLOBAL indices along z)
 inline Range r_slice(const G &g, int i0, int j, int low0) {
     Range r;
     for (int d = 0; d < 3; ++d) {
         if (d >= g.D) { r.lo[d] = r.hi[d] = 0; }
         else if (d == j) { r.lo[d] = r.hi[d] = i0; }
         else { r.lo[d] = low0; r.hi[d] = g.n[d] - 1; }
+    }
+    if (g.D == 3) {
+        if (j == 2) clip_z(g, r, i0, i0);
+        else clip_z(g, r, low0, g.nzg - 1);
     }
     return r;
 }
@@ -258,6 +293,26 @@ __global__ __launch_bounds__(256) void k_finalize(const double *partials, int np
     block_red<NV>(acc, op);
     if (threadIdx.x == 0) fin(acc);
 }
+// distributed variant: local reduction -> red[], (all-reduce over ranks), then the scalar epilogue
+template <int NV>
+__global__ __launch_bounds__(256) void k_reduce_only(const double *partials, int np, int op, double init, double *red) {
+    double acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double a = init;
+        for (int i = threadIdx.x; i < np; i += 256) {
+            double w = partials[(long)q * np + i];
+            a = (op == RED_SUM) ? a + w : (w > a ? w : a);
+        }
+        acc[q] = a;
+    }
+    block_red<NV>(acc, op);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[q] = acc[q];
+    }
+}
+template <class FIN> __global__ void k_apply(const double *red, FIN fin) { fin(red); }
 
 template <class F>
 inline int launch_range(int kclass, const Range &R, F f) {
@@ -270,6 +325,7 @@ inline int launch_range(int kclass, const Range &R, F f) {
 // returns the number of partials per value through *np
 template <int NV, class F>
 inline int launch_range_red(int kclass, const Range &R, F f, double *partials, int op, double init, int *np) {
+    if (R.count() <= 0) { *np = 0; return 0; }  // empty local range (a rank that owns no such plane)
     Tiling t = mk_tiling(R);
     const int nb = grid_for(t);
     *np = nb;
@@ -277,11 +333,36 @@ inline int launch_range_red(int kclass, const Range &R, F f, double *partials, i
     hipLaunchKernelGGL((k_range_red<NV, F>), dim3(nb), dim3(WL_BX * WL_BY), 0, ctx().stream, t, f, partials, op, init);
     return (int)hipGetLastError();
 }
+// `dist`: the reduced quantity lives on a z-slab decomposition -> all-reduce over the ranks before `fin`.
+// `red`: device scratch of >= NV doubles.  fin(const double *vals) runs in one device thread.
 template <int NV, class FIN>
-inline int launch_finalize(const double *partials, int np, int op, double init, FIN fin) {
+inline int launch_finalize(bool dist, const double *partials, int np, int op, double init, double *red, FIN fin) {
     Prof p(WL_K_SCALAR, 0);
-    hipLaunchKernelGGL((k_finalize<NV, FIN>), dim3(1), dim3(256), 0, ctx().stream, partials, np, op, init, fin);
+    Comm *cm = ctx().comm;
+    if (!dist || !cm || cm->size == 1) {
+        hipLaunchKernelGGL((k_finalize<NV, FIN>), dim3(1), dim3(256), 0, ctx().stream, partials, np, op, init, fin);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL((k_reduce_only<NV>), dim3(1), dim3(256), 0, ctx().stream, partials, np, op, init, red);
+    int rc = cm->allreduce(red, NV, op);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_apply<FIN>), dim3(1), dim3(1), 0, ctx().stream, (const double *)red, fin);
     return (int)hipGetLastError();
+}
+// fill the z-halo planes of `ncomp` components from the neighbouring ranks (no-op when not decomposed)
+template <class T> inline int halo_exchange(const G &g, T *a, int ncomp, int depth) {
+    Comm *cm = ctx().comm;
+    if (!g.dist || !cm || cm->size == 1) return 0;
+    const size_t bytes = (size_t)depth * (size_t)g.s[2] * sizeof(T);
+    const bool lo = cm->rank > 0, hi = cm->rank < cm->size - 1;
+    for (int c = 0; c < ncomp; ++c) {
+        T *b = a + (long)c * g.sc;
+        int rc = cm->sendrecv(lo ? b + (long)g.zlo * g.s[2] : nullptr, lo ? b + (long)(g.zlo - depth) * g.s[2] : nullptr,
+                              hi ? b + (long)(g.zhi - depth + 1) * g.s[2] : nullptr,
+                              hi ? b + (long)(g.zhi + 1) * g.s[2] : nullptr, bytes);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------ device math

@@ -58,9 +58,9 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
     const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);  // XCD-contiguous logical id
     const int ch = lb / tpp, pt = lb - ch * tpp;
     const int i0 = 1 + CD_BX * (pt % ntx), j0 = CD_BY * (pt / ntx);
-    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
-    const int k0 = ch * clen, k1 = min(n2, k0 + clen);
-    if (k0 >= n2 || j0 >= n1) return;  // uniform per workgroup (padding tiles)
+    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2], nzg = g.nzg, kz0 = g.kz0;
+    const int k0 = g.zlo + ch * clen, k1 = min(g.zhi + 1, k0 + clen);   // this chunk of the OWNED planes
+    if (k0 > g.zhi || j0 >= n1) return;  // uniform per workgroup (padding tiles)
     const int i = i0 + tx, j = j0 + ty;
     const bool active = (i <= n0 - 2) && (j <= n1 - 1);
     const int ic = min(i, n0 - 1), jc = min(j, n1 - 1);
@@ -127,9 +127,10 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
         }
         // ---- B. fluxes of plane k
         const int s1 = (k + 3) % 3, s0 = (k + 2) % 3;  // LDS slots of planes k and k-1
-        const bool klow = k >= 1;
+        const int kg = k + kz0;                 // plane number in the undecomposed array
+        const bool klow = kg >= 1;
         const bool lowok = jlow && klow;
-        const bool zlb = (k == 1), ztb = (k == n2 - 1);
+        const bool zlb = (kg == 1), ztb = (kg == nzg - 1);
         T rr[3] = {0, 0, 0};
         double Fz[3];
 #pragma unroll
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
                     rr[c] = cd_sub<T>(rr[c], cd_flux<T>(ym1, x0, yp1, yp2, vfu, nu, false, ytb), ytb);
                 }
                 // ---- z lower face of the own cell (cells k <= n2-2 take part in z)
-                if (k <= n2 - 2) rr[c] = cd_add<T>(rr[c], Fz[c], zlb);
+                if (kg <= nzg - 2) rr[c] = cd_add<T>(rr[c], Fz[c], zlb);
             }
         }
         // ---- C. finish and store: the carried cell k-1 gets its upper z flux; cell k is stored now when it
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
             carry = false;
         }
         if (own) {
-            const bool needs_up = lowok && (k <= n2 - 2);
+            const bool needs_up = lowok && (kg <= nzg - 2);
             if (needs_up) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { part[c] = rr[c]; cu0[c] = e0[c]; cV[c] = eV[c]; }
@@ -219,11 +220,12 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, cons
                      bool has_acc) {
     const int ntx = (g.n[0] - 2 + CD_BX - 1) / CD_BX, nty = (g.n[1] + CD_BY - 1) / CD_BY;
     const int tpp = ((ntx * nty + 7) / 8) * 8;  // padded to a multiple of 8 for the XCD mapping (idle tail tiles)
+    const int nown = g.zhi - g.zlo + 1;
     int want = WL_MAXB / tpp;
     if (want < 1) want = 1;
-    if (want > g.n[2]) want = g.n[2];
-    const int clen = (g.n[2] + want - 1) / want;
-    const int nchunk = (g.n[2] + clen - 1) / clen;
+    if (want > nown) want = nown;
+    const int clen = (nown + want - 1) / want;
+    const int nchunk = (nown + clen - 1) / clen;
     const int nblk = tpp * nchunk;
     double a3[3] = {0, 0, 0};
     if (has_acc) for (int d = 0; d < 3; ++d) a3[d] = acc[d];

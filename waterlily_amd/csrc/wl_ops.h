@@ -17,6 +17,7 @@ struct State {
     double shift;             // residual! mean
     double r2;                // L2(p)
     double out[4];            // generic scalar outputs (cfl dt, dot, sum, ...)
+    double red[4];            // reduction staging for the cross-rank all-reduce
     int active;               // pcg still running
     int do_shift;             // residual! must subtract the mean
     int nupd;                 // number of (x,r) updates pcg performed
@@ -39,8 +40,10 @@ int op_bc_vec(const G &g, T *a, const double *A, int saveexit, int permask) {
         for (int j = 0; j < D; ++j) {
             T *ac = a + (long)c * g.sc;
             const long sj = g.s[j];
-            const int N = g.n[j];
+            const int N = (j == 2) ? g.nzg : g.n[j];   // plane numbers along z are global
             const G gg = g;
+            if (((permask >> j) & 1) && j == 2 && g.dist)
+                return fail(WL_E_ARG, "periodic z is not supported on a z-slab decomposition", __FILE__, __LINE__);
             if ((permask >> j) & 1) {
                 const long off = (long)(N - 2) * sj;
                 WL_TRY(launch_range(WL_K_BC, r_slice(g, 0, j, 0), [=] __device__(int i, int jj, int k) {
@@ -70,6 +73,7 @@ template <class T, int D>
 int op_bc_per(const G &g, T *a, int permask) {
     for (int j = 0; j < D; ++j)
         if ((permask >> j) & 1) {
+            if (j == 2 && g.dist) return fail(WL_E_ARG, "periodic z is not supported on a z-slab decomposition", __FILE__, __LINE__);
             const long off = (long)(g.n[j] - 2) * g.s[j];
             const G gg = g;
             WL_TRY(launch_range(WL_K_BC, r_slice(g, 0, j, 0), [=] __device__(int i, int jj, int k) {
@@ -77,7 +81,9 @@ int op_bc_per(const G &g, T *a, int permask) {
             WL_TRY(launch_range(WL_K_BC, r_slice(g, g.n[j] - 1, j, 0), [=] __device__(int i, int jj, int k) {
                 const long I = gg.at(i, jj, k); a[I] = a[I - off]; }));
         }
-    return 0;
+    // z-slab decomposition: the reference calls perBC! exactly where a stencil operand's ghosts must be current
+    // (mult!, residual!, increment!, pcg!, end of solver!), which is also where the z halos must be exchanged
+    return halo_exchange<T>(g, a, 1, 1);
 }
 
 // exitBC!(u,u0,U,dt)  src/util.jl:216-222
@@ -89,6 +95,7 @@ int op_exit_bc(const G &g, T *u, const T *u0, const double *U, double dt_, doubl
         else if (d == 0) { R.lo[d] = R.hi[d] = g.n[0] - 1; }
         else { R.lo[d] = 1; R.hi[d] = g.n[d] - 2; }
     }
+    clip_z(g, R, 1, g.nzg - 2);
     const T U1 = (T)U[0], Udt = U1 * (T)dt_;
     const G gg = g;
     int np = 0;
@@ -98,8 +105,8 @@ int op_exit_bc(const G &g, T *u, const T *u0, const double *U, double dt_, doubl
         u[I] = v;
         acc[0] += (double)v;
     }, partials, RED_SUM, 0.0, &np)));
-    const T cnt = (T)R.count();
-    WL_TRY((launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) {
+    const T cnt = (T)((long)(g.n[1] - 2) * (D > 2 ? (long)(g.nzg - 2) : 1L));  // length(exitR) of the whole domain
+    WL_TRY((launch_finalize<1>(g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
         st->out[0] = (double)((T)v[0] / cnt - U1); })));
     return launch_range(WL_K_BC, R, [=] __device__(int i, int j, int k) { u[gg.at(i, j, k)] -= (T)st->out[0]; });
 }
@@ -113,7 +120,7 @@ int op_reduce(const G &g, int kclass, int op, double init, F cell, double *parti
         const double v = cell(gg.at(i, j, k));
         acc[0] = (op == RED_SUM) ? acc[0] + v : (v > acc[0] ? v : acc[0]);
     }, partials, op, init, &np)));
-    return launch_finalize<1>(partials, np, op, init, [=] __device__(double(&v)[1]) { st->out[slot] = v[0]; });
+    return launch_finalize<1>(g.dist, partials, np, op, init, st->red, [=] __device__(const double *v) { st->out[slot] = v[0]; });
 }
 
 // ------------------------------------------------------------------------------------------ Flow.jl
@@ -132,7 +139,7 @@ int op_conv_diff_range(const G &g, const Range &R, T *r, const T *u, double nu_,
     const G gg = g;
     return launch_range(WL_K_CONVDIFF, R, [=] __device__(int i, int j, int k) {
         const long I = gg.at(i, j, k);
-        const int idx[3] = {i, j, k};
+        const int idx[3] = {i, j, gg.kg(k)};   // z index in global numbering
         bool lowok = true;
 _Pragma("unroll")
         for (int d = 0; d < D; ++d) lowok = lowok && idx[d] >= 1;
@@ -144,7 +151,7 @@ _Pragma("unroll")
             if (lowok) {
 _Pragma("unroll")
                 for (int jd = 0; jd < D; ++jd) {
-                    const int Nj = gg.n[jd];
+                    const int Nj = (jd == 2) ? gg.nzg : gg.n[jd];
                     if (idx[jd] > Nj - 2) continue;
                     const T *uj = u + (long)jd * gg.sc;
                     const long sj = gg.s[jd];
@@ -348,7 +355,7 @@ _Pragma("unroll")
         acc[0] = (double)sg > acc[0] ? (double)sg : acc[0];
     }, partials, RED_MAX, -1e300, &np)));
     const T nu5 = (T)5 * (T)nu_;
-    return launch_finalize<1>(partials, np, RED_MAX, -1e300, [=] __device__(double(&v)[1]) {
+    return launch_finalize<1>(g.dist, partials, np, RED_MAX, -1e300, st->red, [=] __device__(const double *v) {
         const T d = (T)1 / ((T)v[0] + nu5);
         st->out[0] = (double)(d < (T)10 ? d : (T)10);
     });
@@ -396,7 +403,7 @@ int op_residual(const LevelT<T> &p, int permask, double *partials, State *st) {
     }, partials, RED_SUM, 0.0, &np)));
     const T cnt = (T)p.g.interior_cells();
     const T eps2 = (T)2 * Lim<T>::eps;
-    WL_TRY((launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) {
+    WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
         const T s = (T)v[0] / cnt;
         st->shift = (double)s;
         st->do_shift = !((s < 0 ? -s : s) <= eps2);
@@ -450,7 +457,7 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st)
         q.z[I] = v; q.eps[I] = v;
         acc[0] += (double)q.r[I] * (double)v;
     }, partials, RED_SUM, 0.0, &np)));
-    WL_TRY((launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) {
+    WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
         const T rho = (T)v[0];
         st->rho = (double)rho;
         st->nupd = 0;
@@ -466,7 +473,7 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st)
             q.z[I] = v;
             acc[0] += (double)v * (double)q.eps[I];
         }, partials, RED_SUM, 0.0, &np)));
-        WL_TRY((launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) {
+        WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
             if (!st->active) return;
             const T alpha = (T)st->rho / (T)v[0];
             const double aa = (double)(alpha < 0 ? -alpha : alpha);
@@ -488,7 +495,7 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st)
                 acc[0] += (double)rn * (double)zn;
             }
         }, partials, RED_SUM, 0.0, &np)));
-        WL_TRY((launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) {
+        WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
             if (!st->active) return;
             st->nupd += 1;
             if (last) { st->active = 0; return; }  // :135
@@ -517,10 +524,24 @@ int op_L2(const LevelT<T> &p, double *partials, State *st) {
         const double v = (double)q.r[q.g.at(i, j, k)];
         acc[0] += v * v;
     }, partials, RED_SUM, 0.0, &np)));
-    return launch_finalize<1>(partials, np, RED_SUM, 0.0, [=] __device__(double(&v)[1]) { st->r2 = (double)(T)v[0]; });
+    return launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) { st->r2 = (double)(T)v[0]; });
 }
 
 // ------------------------------------------------------------------------------------------ MultiLevelPoisson.jl
+// interior coarse cells whose 2^D children (up(I), MultiLevelPoisson.jl:1) are all OWNED fine cells of this rank.
+// Not decomposed: exactly inside(a).  Also valid when the coarse array is replicated and the fine one a slab.
+inline Range r_children(const G &ga, const G &gb) {
+    Range R = r_inside(ga);
+    if (ga.D == 3) {
+        const int flo = (gb.zlo + gb.kz0) > 1 ? (gb.zlo + gb.kz0) : 1;
+        const int fhi = (gb.zhi + gb.kz0) < gb.nzg - 2 ? (gb.zhi + gb.kz0) : gb.nzg - 2;
+        const int clo = (flo + 2) / 2 - ga.kz0, chi = fhi / 2 - ga.kz0;   // 2c-1 >= flo, 2c <= fhi
+        if (clo > R.lo[2]) R.lo[2] = clo;
+        if (chi < R.hi[2]) R.hi[2] = chi;
+    }
+    return R;
+}
+
 // restrictL!  src/MultiLevelPoisson.jl:10-16,26-32
 template <class T, int D>
 int op_restrictL(const G &ga, T *a, const G &gb, const T *b, int permask) {
@@ -528,14 +549,15 @@ int op_restrictL(const G &ga, T *a, const G &gb, const T *b, int permask) {
         T *ac = a + (long)c * ga.sc;
         const T *bc = b + (long)c * gb.sc;
         const G A = ga, B = gb;
-        WL_TRY(launch_range(WL_K_RESTRICTL, r_inside(ga), [=] __device__(int i, int j, int k) {
-            const int cc[3] = {i, j, k};
+        WL_TRY(launch_range(WL_K_RESTRICTL, r_children(ga, gb), [=] __device__(int i, int j, int k) {
+            const int cc[3] = {i, j, A.kg(k)};
             int lo[3], hi[3];
 _Pragma("unroll")
             for (int d = 0; d < 3; ++d) {
                 if (d >= D) { lo[d] = hi[d] = 0; }
                 else { lo[d] = 2 * cc[d] - 1; hi[d] = (d == c) ? lo[d] : 2 * cc[d]; }
             }
+            lo[2] -= B.kz0; hi[2] -= B.kz0;   // fine planes: global -> local
             T s = 0;
             for (int kk = lo[2]; kk <= hi[2]; ++kk)
                 for (int jj = lo[1]; jj <= hi[1]; ++jj)
@@ -543,17 +565,33 @@ _Pragma("unroll")
             ac[A.at(i, j, k)] = (T)(0.5 * (double)s);
         }));
     }
+    (void)permask;
+    return 0;   // BC!(a,0) (MultiLevelPoisson.jl:31) is applied by the caller after the slab hand-over, see coarse_L_finish
+}
+// second half of restrictL!: (multi-GPU hand-over of the owned planes), then BC!(aL, 0) (:31), then halos
+template <class T, int D>
+int coarse_L_finish(const G &ga, T *a, const G &gb, int permask) {
+    Comm *cm = ctx().comm;
+    if (cm && cm->size > 1 && gb.dist && !ga.dist) {
+        // fine level decomposed, coarse level replicated: all-gather the planes each rank restricted
+        const int nzl = (gb.nzg - 2) / cm->size / 2;   // coarse planes per rank
+        for (int c = 0; c < D; ++c) {
+            int rc = cm->allgather(a + (long)c * ga.sc + ga.s[2], (size_t)nzl * ga.s[2] * sizeof(T));
+            if (rc) return rc;
+        }
+    }
     const double zero[3] = {0, 0, 0};
-    return op_bc_vec<T, D>(ga, a, zero, 0, permask);
+    WL_TRY((op_bc_vec<T, D>(ga, a, zero, 0, permask)));
+    return halo_exchange<T>(ga, a, D, 1);
 }
 
 // restrict!  src/MultiLevelPoisson.jl:3-9,33 : coarse = SUM of the 2^D children (x fastest)
 template <class T, int D>
 int op_restrict(const G &ga, T *a, const G &gb, const T *b) {
     const G A = ga, B = gb;
-    return launch_range(WL_K_RESTRICT, r_inside(ga), [=] __device__(int i, int j, int k) {
+    return launch_range(WL_K_RESTRICT, r_children(ga, gb), [=] __device__(int i, int j, int k) {
         T s = 0;
-        const int k0 = D > 2 ? 2 * k - 1 : 0, k1 = D > 2 ? 2 * k : 0;
+        const int k0 = D > 2 ? 2 * A.kg(k) - 1 - B.kz0 : 0, k1 = D > 2 ? 2 * A.kg(k) - B.kz0 : 0;
         for (int kk = k0; kk <= k1; ++kk)
             for (int jj = 2 * j - 1; jj <= 2 * j; ++jj)
                 for (int ii = 2 * i - 1; ii <= 2 * i; ++ii) s += b[B.at(ii, jj, kk)];
@@ -566,7 +604,7 @@ template <class T, int D>
 int op_prolongate(const G &ga, T *a, const G &gb, const T *b) {
     const G A = ga, B = gb;
     return launch_range(WL_K_PROLONG, r_inside(ga), [=] __device__(int i, int j, int k) {
-        a[A.at(i, j, k)] = b[B.at((i + 1) / 2, (j + 1) / 2, D > 2 ? (k + 1) / 2 : 0)];
+        a[A.at(i, j, k)] = b[B.at((i + 1) / 2, (j + 1) / 2, D > 2 ? (A.kg(k) + 1) / 2 - B.kz0 : 0)];
     });
 }
 

@@ -1,0 +1,123 @@
+"""Multi-GPU bootstrap: z-slab decomposition, one process per GPU.
+
+The data path (halo planes, scalar all-reduces, coarse-level all-gather) lives in libwlhip.so and runs over RCCL
+(xGMI) on the compute stream.  This module only (a) computes the slab partition, (b) bootstraps the RCCL
+communicator by broadcasting the 128-byte unique id through torch.distributed, and (c) provides the *host-callback*
+communicator used by tests, where the same C++ code paths are driven over torch.distributed `gloo` (several ranks
+may then share one GPU, or -- for the pure host-logic tests -- no GPU at all).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+HZ = 2  # halo depth of a decomposed array: QUICK reads I-2..I+1 across a face (src/Flow.jl:6)
+
+
+@dataclass
+class Slab:
+    """Partition of the z axis (interior extent nz) over `size` ranks for ONE grid level."""
+    rank: int
+    size: int
+    nz: int                      # global interior planes of this level
+
+    def __post_init__(self):
+        if self.nz % self.size:
+            raise ValueError(f"z extent {self.nz} is not divisible by {self.size} ranks")
+        self.nzl = self.nz // self.size           # interior planes per rank
+        self.n2l = self.nzl + 2 * HZ              # local planes incl. halo
+        self.nzg = self.nz + 2                    # global planes incl. the ghost layer
+        self.kz0 = self.rank * self.nzl + 1 - HZ  # global index of local plane 0
+        self.own_lo = HZ - (1 if self.rank == 0 else 0)                 # rank 0 owns the lower ghost plane
+        self.own_hi = HZ + self.nzl - 1 + (1 if self.rank == self.size - 1 else 0)
+
+    def coarser(self) -> Optional["Slab"]:
+        """The slab of the next multigrid level, or None when that level must be replicated
+        (children of a coarse cell must live on one rank, and a slab needs >= 2 planes)."""
+        if self.nzl % 2 or self.nzl // 2 < 2:
+            return None
+        return Slab(self.rank, self.size, self.nz // 2)
+
+
+_state = {"kind": None, "rank": 0, "size": 1, "keep": None}
+
+
+def rank_size():
+    return _state["rank"], _state["size"]
+
+
+def init_rccl() -> None:
+    """Bootstrap the RCCL communicator inside libwlhip.so (torch.distributed must be initialised)."""
+    import torch.distributed as dist
+    L = _lib.lib()
+    rank, size = dist.get_rank(), dist.get_world_size()
+    buf = (C.c_char * 128)()
+    if rank == 0:
+        _lib.check(L.wl_comm_unique_id(buf))
+    obj = [bytes(buf)]
+    dist.broadcast_object_list(obj, src=0)
+    raw = (C.c_char * 128).from_buffer_copy(obj[0])
+    _lib.check(L.wl_comm_init_rccl(raw, rank, size))
+    _state.update(kind="rccl", rank=rank, size=size)
+
+
+def host_callbacks(group=None):
+    """ctypes callbacks that carry libwlhip's collectives over torch.distributed on HOST buffers."""
+    import torch
+    import torch.distributed as dist
+    rank, size = dist.get_rank(group), dist.get_world_size(group)
+
+    def view(ptr, nbytes):
+        return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,)))
+
+    def sendrecv(user, slo, rlo, shi, rhi, nbytes):
+        try:
+            ops = []
+            if slo:
+                ops += [dist.P2POp(dist.isend, view(slo, nbytes), rank - 1, group), dist.P2POp(dist.irecv, view(rlo, nbytes), rank - 1, group)]
+            if shi:
+                ops += [dist.P2POp(dist.isend, view(shi, nbytes), rank + 1, group), dist.P2POp(dist.irecv, view(rhi, nbytes), rank + 1, group)]
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print("wl host sendrecv failed:", e, flush=True)
+            return 1
+
+    def allreduce(user, vals, n, op):
+        try:
+            t = torch.from_numpy(np.ctypeslib.as_array(vals, shape=(n,)))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=group)
+            return 0
+        except Exception as e:
+            print("wl host allreduce failed:", e, flush=True)
+            return 1
+
+    def allgather(user, buf, nbytes):
+        try:
+            full = view(buf, nbytes * size)
+            mine = full[rank * nbytes:(rank + 1) * nbytes].clone()
+            dist.all_gather_into_tensor(full, mine, group=group)
+            return 0
+        except Exception as e:
+            print("wl host allgather failed:", e, flush=True)
+            return 1
+
+    return _lib.SENDRECV_FN(sendrecv), _lib.ALLREDUCE_FN(allreduce), _lib.ALLGATHER_FN(allgather), rank, size
+
+
+def init_host(group=None) -> None:
+    """Install the host-callback communicator (tests; transport = whatever backend `group` uses, e.g. gloo)."""
+    sr, ar, ag, rank, size = host_callbacks(group)
+    _lib.check(_lib.lib().wl_comm_init_host(rank, size, sr, ar, ag, None))
+    _state.update(kind="host", rank=rank, size=size, keep=(sr, ar, ag))
+
+
+def finalize() -> None:
+    _lib.check(_lib.lib().wl_comm_finalize())
+    _state.update(kind=None, rank=0, size=1, keep=None)

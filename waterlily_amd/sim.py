@@ -46,8 +46,12 @@ class Layout:
     offset so that element [1,j,k] (first interior cell of a row) is 128-B aligned; padded=False is the
     reference's dense column-major layout."""
 
-    def __init__(self, Ng: Sequence[int], T, padded: bool = True):
-        self.Ng = tuple(int(n) for n in Ng)
+    def __init__(self, Ng: Sequence[int], T, padded: bool = True, slab=None):
+        """Ng: extents of the UNDECOMPOSED array (ghosts included).  slab (dist.Slab, D==3 only): this rank's
+        z-slab -- the local array then has slab.n2l planes (interior share + 2-plane halos)."""
+        self.slab = slab
+        self.Ng_global = tuple(int(n) for n in Ng)
+        self.Ng = tuple(int(n) for n in Ng) if slab is None else tuple(int(n) for n in Ng[:2]) + (slab.n2l,)
         self.D = len(self.Ng)
         self.T = np.dtype(T)
         n = self.Ng + (1,) * (3 - self.D)
@@ -71,6 +75,8 @@ class Layout:
         g.n[:] = list(self.n3)
         g.s[:] = list(self.s)
         g.sc = self.sc
+        if self.slab is not None:
+            g.nzg, g.kz0, g.own_lo, g.own_hi = self.slab.nzg, self.slab.kz0, self.slab.own_lo, self.slab.own_hi
         return g
 
     def alloc(self, ncomp: Sequence[int], device, fill: float = 0.0) -> torch.Tensor:
@@ -83,7 +89,9 @@ class Layout:
         for _ in ncomp:
             stride += (cs,)
             cs *= ncomp[0]
-        return torch.as_strided(buf, size, stride, self.lead)
+        a = torch.as_strided(buf, size, stride, self.lead)
+        a._wl_slab = self.slab
+        return a
 
 
 def _grid_of(a: torch.Tensor, D: int) -> Grid:
@@ -96,6 +104,9 @@ def _grid_of(a: torch.Tensor, D: int) -> Grid:
     s = list(st) + [st[-1] * n[D - 1]] * (3 - D)
     g.s[:] = s
     g.sc = a.stride()[D] if a.ndim > D else s[D - 1] * n[D - 1]
+    sl = getattr(a, "_wl_slab", None)
+    if sl is not None:
+        g.nzg, g.kz0, g.own_lo, g.own_hi = sl.nzg, sl.kz0, sl.own_lo, sl.own_hi
     return g
 
 
@@ -126,9 +137,12 @@ def permask(perdir: Sequence[int]) -> int:
 
 # --------------------------------------------------------------------------- util.jl
 
-def loc(i: int, shape: Sequence[int]) -> np.ndarray:
-    """util.jl:160 for every index of an array of extents `shape` (i=-1: cell centre)."""
+def loc(i: int, shape: Sequence[int], kz0: int = 0) -> np.ndarray:
+    """util.jl:160 for every index of an array of extents `shape` (i=-1: cell centre); kz0 = global index of
+    local plane 0 when `shape` is a z-slab."""
     ax = [np.arange(n, dtype=np.float64) - 0.5 for n in shape]
+    if kz0:
+        ax[-1] = ax[-1] + kz0
     x = np.stack(np.meshgrid(*ax, indexing="ij"))
     if i >= 0:
         x[i] -= 0.5
@@ -139,8 +153,10 @@ def apply_vec(f: Callable, c: torch.Tensor) -> None:
     """util.jl:171 applyV! -- runs the user's closure on the host, then uploads."""
     D = c.ndim - 1
     h = np.zeros(tuple(c.shape), dtype=_T(c), order="F")
+    sl = getattr(c, "_wl_slab", None)
     for i in range(D):
-        h[..., i] = np.broadcast_to(np.asarray(f(i, loc(i, c.shape[:-1])), dtype=np.float64), c.shape[:-1])
+        x = loc(i, c.shape[:-1], sl.kz0 if sl is not None else 0)
+        h[..., i] = np.broadcast_to(np.asarray(f(i, x), dtype=np.float64), c.shape[:-1])
     upload(c, h)
 
 
@@ -166,6 +182,30 @@ def perBC(a: torch.Tensor, perdir: Sequence[int]) -> None:
     """util.jl:227-231"""
     g = _grid_of(a, a.ndim)
     check(_lib.lib().wl_bc_per(_WLT[_T(a)], C.byref(g), _ptr(a), permask(perdir)))
+
+
+def halo_exchange(a: torch.Tensor, depth: int = 2) -> None:
+    """Fill the z-halo planes of a decomposed field from the neighbouring ranks (no-op when not decomposed)."""
+    sl = getattr(a, "_wl_slab", None)
+    if sl is None:
+        return
+    D = 3
+    ncomp = int(np.prod(a.shape[D:])) if a.ndim > D else 1
+    g = _grid_of(a, D)
+    check(_lib.lib().wl_halo_exchange(_WLT[_T(a)], C.byref(g), _ptr(a), ncomp, depth))
+
+
+def gather(a: torch.Tensor) -> np.ndarray:
+    """Assemble the undecomposed host array from the owned planes of every rank (tests / output)."""
+    sl = getattr(a, "_wl_slab", None)
+    h = to_host(a)
+    if sl is None or sl.size == 1:
+        return h
+    import torch.distributed as dist
+    mine = np.ascontiguousarray(np.moveaxis(h, 2, 0)[sl.own_lo:sl.own_hi + 1])
+    parts = [None] * sl.size
+    dist.all_gather_object(parts, mine)
+    return np.asfortranarray(np.moveaxis(np.concatenate(parts, axis=0), 0, 2))
 
 
 def exitBC(u: torch.Tensor, u0: torch.Tensor, U, dt: float) -> None:
@@ -206,13 +246,16 @@ class Flow:
     """src/Flow.jl:92-122.  Fields: u, u0, f, V, mu0 (Ng...,D); mu1 (Ng...,D,D); p, sigma (Ng...)."""
 
     def __init__(self, N, U, *, dt=0.25, nu=0.0, g=None, ulam=None, perdir=(), exitBC=False, T=np.float64,
-                 device="cuda:0", padded=True):
+                 device="cuda:0", padded=True, slab=None):
         self.device = _require_gpu(device)
         D = len(N)
         self.D, self.T = D, np.dtype(T)
         Ng = tuple(int(n) + 2 for n in N)
-        self.N = Ng
-        self.layout = Layout(Ng, T, padded)
+        self.N = Ng                      # extents of the undecomposed arrays (the reference's size(p))
+        self.slab = slab
+        if slab is not None and (D != 3 or 2 in tuple(perdir)):
+            raise ValueError("z-slab decomposition needs D == 3 and a non-periodic z direction")
+        self.layout = Layout(Ng, T, padded, slab)
         self.U, self.g, self.nu = U, g, float(nu)
         self.perdir, self.exitBC = tuple(int(j) for j in perdir), bool(exitBC)
         self.dt = [float(self.T.type(dt))]
@@ -222,11 +265,13 @@ class Flow:
         U0 = BCTuple(U, [0.0], D)
         BC(self.u, U0, exitBC, perdir)
         _exit_bc(self.u, self.u, U0, 0.0)
+        halo_exchange(self.u, 2)
         self.u0 = al((D,))
         self.u0.copy_(self.u)
         self.f, self.p, self.sigma = al((D,)), al(()), al(())
         self.V, self.mu0, self.mu1 = al((D,)), al((D,), 1.0), al((D, D))
         BC(self.mu0, (0.0,) * D, False, perdir)
+        halo_exchange(self.mu0, 2)
         desc = FlowDesc()
         desc.g = self.layout.grid()
         for k in ("u", "u0", "f", "p", "sigma", "V", "mu0", "mu1"):
@@ -288,7 +333,7 @@ class _Level:
     def __init__(self, lay: Layout, x, L, z, device):
         self.layout, self.x, self.L, self.z = lay, x, L, z
         self.D, self.iD, self.eps, self.r = (lay.alloc((), device) for _ in range(4))
-        self.shape = lay.Ng
+        self.shape = lay.Ng_global
 
     def desc(self) -> LevelDesc:
         d = LevelDesc()
@@ -300,7 +345,9 @@ class _Level:
 
 def _layout_of(x: torch.Tensor) -> Layout:
     D = x.ndim
-    lay = Layout(tuple(x.shape), _T(x), padded=False)
+    sl = getattr(x, "_wl_slab", None)
+    shape = tuple(x.shape) if sl is None else tuple(x.shape[:2]) + (sl.nzg,)
+    lay = Layout(shape, _T(x), padded=False, slab=sl)
     st = tuple(x.stride())
     n = lay.n3
     lay.s = (1, st[1], st[2] if D == 3 else st[1] * n[1])
@@ -356,10 +403,14 @@ class MultiLevelPoisson(_PoissonBase):
         lay = _layout_of(x)
         lay.sc = L.stride(-1)
         levels = [_Level(lay, x, L, z, x.device)]
-        # restrictML, MultiLevelPoisson.jl:18-25,53-55
-        while _divisible(levels[-1].shape) and len(levels) <= maxlevels:
-            Na = tuple(1 + n // 2 for n in levels[-1].shape)
-            la = Layout(Na, self.T, padded)
+        # restrictML, MultiLevelPoisson.jl:18-25,53-55.  Multi-GPU: a level stays a z-slab while every rank keeps
+        # >= 2 (even) planes; coarser levels are REPLICATED on every rank (all-gather at the hand-over), which
+        # keeps the hierarchy -- and hence the iteration counts -- identical to the single-device one.
+        slab = lay.slab
+        while _divisible(levels[-1].layout.Ng_global) and len(levels) <= maxlevels:
+            Na = tuple(1 + n // 2 for n in levels[-1].layout.Ng_global)
+            slab = slab.coarser() if slab is not None else None
+            la = Layout(Na, self.T, padded, slab)
             levels.append(_Level(la, la.alloc((), x.device), la.alloc((D,), x.device), la.alloc((), x.device), x.device))
         if len(levels) <= 2:
             raise AssertionError("MultiLevelPoisson requires size=a2ⁿ, where n>2")
@@ -462,7 +513,7 @@ class Simulation:
     """src/WaterLily.jl:59-79"""
 
     def __init__(self, dims, u_BC, L, *, dt=0.25, nu=0.0, g=None, U=None, eps=1, perdir=(), ulam=None,
-                 exitBC=False, body=None, T=np.float32, device="cuda:0", padded=True):
+                 exitBC=False, body=None, T=np.float32, device="cuda:0", padded=True, slab="auto"):
         assert not (callable(u_BC) and callable(ulam)), "`u_BC` and `uλ` cannot be both specified as Function"
         assert not (U is None and callable(u_BC)), "`U` must be specified if `u_BC` is a Function"
         if ulam is None:
@@ -470,8 +521,13 @@ class Simulation:
         self.U = float(np.sqrt(sum(float(v) ** 2 for v in u_BC))) if U is None else U
         self.L, self.eps = L, eps
         self.body = body if body is not None else B.NoBody()
+        if slab == "auto":   # one z-slab per rank once a communicator exists (waterlily_amd.dist.init_*)
+            from . import dist as _dist
+            r, n = _dist.rank_size()
+            slab = _dist.Slab(r, n, int(dims[2])) if (n > 1 and len(dims) == 3) else None
+        self.slab = slab
         self.flow = Flow(dims, u_BC, ulam=ulam, dt=dt, nu=nu, g=g, T=T, perdir=perdir, exitBC=exitBC,
-                         device=device, padded=padded)
+                         device=device, padded=padded, slab=slab)
         self._band = None
         measure_flow(self.flow, self.body, t=0.0, eps=eps)
         self.pois = MultiLevelPoisson(self.flow.p, self.flow.mu0, self.flow.sigma, perdir=perdir, padded=padded)
@@ -482,13 +538,15 @@ def measure_flow(a: Flow, body, t=0.0, eps=1) -> None:
     fields are uploaded and the two BC! calls run on the device."""
     if isinstance(body, B.NoBody):
         return
-    mu0, mu1, V, d = B.measure_fields(body, tuple(n - 2 for n in a.N), t=t, eps=eps, T=a.T)
+    mu0, mu1, V, d = B.measure_fields(body, tuple(n - 2 for n in a.N), t=t, eps=eps, T=a.T, slab=a.slab)
     upload(a.mu0, mu0)
     upload(a.mu1, mu1)
     upload(a.V, V)
     a.sigma[inside(a.sigma)] = torch.from_numpy(np.ascontiguousarray(d[inside(d)])).to(a.sigma.device)
     BC(a.mu0, (0.0,) * a.D, False, a.perdir)
     BC(a.V, (0.0,) * a.D, a.exitBC, a.perdir)
+    halo_exchange(a.mu0, 2)   # (mu1 needs no exchange: the host evaluated the halo planes from the sdf directly)
+    halo_exchange(a.V, 2)
 
 
 def sim_time(sim: Simulation) -> float:
@@ -541,6 +599,6 @@ def band_to_device(p: torch.Tensor, idx: np.ndarray, nds: np.ndarray):
 def pressure_force(sim: Simulation) -> np.ndarray:
     """Metrics.jl:94-95"""
     if sim._band is None or sim._band[0] != time(sim.flow):
-        idx, nds = B.nds_band(sim.body, tuple(n - 2 for n in sim.flow.N), t=time(sim.flow))
+        idx, nds = B.nds_band(sim.body, tuple(n - 2 for n in sim.flow.N), t=time(sim.flow), slab=sim.slab)
         sim._band = (time(sim.flow),) + band_to_device(sim.flow.p, idx, nds)
     return pressure_force_band(sim.flow.p, sim._band[1], sim._band[2])
