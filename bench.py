@@ -50,13 +50,17 @@ ALG_T = {
 }
 
 
-def sphere(n, m, T, Re=3700.0, device="cuda:0"):
-    """reference README.md:118-125: radius=m/8, center=m/2-1, L=2radius, nu=U*L/Re"""
+def sphere(dims, T, Re=3700.0, device="cuda:0"):
+    """reference README.md:118-125: radius=m/8, center=m/2-1, L=2radius, nu=U*L/Re (m = shortest side; the
+    sphere sits at the same x,y position and in the middle of the z extent)"""
+    import torch
     from waterlily_amd import sim as S
     from waterlily_amd.body import AutoBody, norm2
-    radius, center = m / 8, m / 2 - 1
-    body = AutoBody(lambda x, t: norm2(x - center) - radius)
-    return S.Simulation((n, m, m), (1.0, 0.0, 0.0), 2 * radius, nu=2 * radius / Re, body=body, T=T, device=device)
+    m = min(dims)
+    radius = m / 8
+    c = torch.tensor([m / 2 - 1, dims[1] / 2 - 1, dims[2] / 2 - 1], dtype=torch.float64)[:, None]
+    body = AutoBody(lambda x, t: norm2(x - c) - radius)
+    return S.Simulation(tuple(dims), (1.0, 0.0, 0.0), 2 * radius, nu=2 * radius / Re, body=body, T=T, device=device)
 
 
 def cpu_baseline(size: int, steps: int):
@@ -103,6 +107,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default=None, help="force the kernel class reported in `roofline`")
+    ap.add_argument("--grid", type=int, nargs=3, default=None,
+                    help="explicit GLOBAL grid nx ny nz (strong scaling, e.g. 1024 1024 512 = BASELINE configs[3])")
     args = ap.parse_args()
 
     import torch
@@ -111,22 +117,35 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.gpus > 1:
-        raise SystemExit("bench.py: the z-slab multi-GPU path is not wired into bench.py yet (round 1: N=1)")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
 
     from waterlily_amd import _lib
+    from waterlily_amd import dist as wd
     from waterlily_amd import sim as S
     L = _lib.lib()
     T = np.float32 if args.dtype == "f32" else np.float64
     tsz = np.dtype(T).itemsize
     dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    if world > 1:
+        # one process per GPU; the z axis is cut into `world` slabs, halos + scalar all-reduces run over RCCL (xGMI)
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+        wd.init_rccl()
     m = args.size
-    sim = sphere(m, m, T, device=dev)
-    ncell = m ** 3
+    # N=1: the BASELINE 512^3 cube.  N>1 (default): WEAK scaling -- every GPU keeps a 512x512x512 slab, i.e. the
+    # global grid is 512 x 512 x 512N; --grid gives an explicit global grid instead (strong scaling).
+    dims = tuple(args.grid) if args.grid else (m, m, m * world)
+    scaling = "strong" if args.grid else "weak"
+    sim = sphere(dims, T, device=dev)
+    ncell_global = int(np.prod(dims))
+    ncell = ncell_global // world            # cells per rank: threshold for "finest level" launches
     names = class_table(L)
 
     def sync():
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
 
     # warm-up; the last warm-up step times EVERY finest-level launch with hipEvents to find the dominant kernel
     per_class = {}
@@ -157,12 +176,16 @@ def main():
         S.sim_step(sim, remeasure=False)
     sync()
     elapsed = time.perf_counter() - t0
+    if world > 1:  # MAX over ranks
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
     nl, nc, ms = C.c_int64(), C.c_int64(), C.c_double()
     _lib.check(L.wl_prof_timed(C.byref(nl), C.byref(nc), C.byref(ms)))
     _lib.check(L.wl_prof_select(-1, 0))
     vcycles = sim.pois.n[n0:]
 
-    mlups = ncell * args.steps / elapsed / 1e6
+    mlups = ncell_global * args.steps / elapsed / 1e6
     avg_ms = ms.value / max(1, nl.value)
     alg_bytes = ALG_T[dominant] * tsz * (nc.value / max(1, nl.value))
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -170,24 +193,29 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(f"{dominant}@{m}^3/{args.dtype}")
+            traffic = json.load(open(tfile)).get(f"{dominant}@{m}^3/{args.dtype}") if not args.grid else None
         except Exception:
             traffic = None
     out = {
         "metric": "MLUPS (cell-updates/s) per sim_step!, 3D sphere", "value": mlups, "unit": "MLUPS",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"3D sphere {m}^3, Re=3700, {args.dtype}, uniform inflow, remeasure=false "
-                               f"(BASELINE configs[2])", "vcycles_per_solve": vcycles[:6],
-                   "mean_vcycles_per_step": float(np.sum(vcycles)) / args.steps},
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"3D sphere {dims[0]}x{dims[1]}x{dims[2]}, Re=3700, {args.dtype}, uniform inflow, "
+                               f"remeasure=false" + (" (BASELINE configs[2])" if world == 1 and not args.grid else
+                                                     f", z-slabs over {world} GPUs (RCCL halo exchange)"),
+                   "vcycles_per_solve": vcycles[:6], "mean_vcycles_per_step": float(np.sum(vcycles)) / args.steps},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": nl.value,
                      "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "per_class_ms_one_step": per_class},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps)
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        wd.finalize()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

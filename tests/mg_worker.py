@@ -20,9 +20,14 @@ from waterlily_amd.body import AutoBody, norm2  # noqa: E402
 
 def main():
     case = sys.argv[1] if len(sys.argv) > 1 else "sphere_f32"
-    dist.init_process_group("gloo")
+    if "rccl" in case:   # the production transport (one GPU per rank; world size 1 on a 1-GPU box)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+        wd.init_rccl()
+    else:
+        dist.init_process_group("gloo")
+        wd.init_host()
     rank, size = dist.get_rank(), dist.get_world_size()
-    wd.init_host()
     T = np.float64 if case.endswith("f64") else np.float32
     m = 32
     dims = (m, m, m) if "long" not in case else (m, m, 2 * m)
@@ -39,7 +44,8 @@ def main():
     kw = dict(nu=nu, body=body, T=T, exitBC=("exit" in case))
     ref = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=None, **kw)
     slab = wd.Slab(rank, size, dims[2])
-    sim = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=slab, **kw)
+    # "deep": keep every level a slab as long as the partition allows; default: replicate levels <= 2^21 cells
+    sim = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=slab, replicate_cells=0 if "deep" in case else 1 << 21, **kw)
     out = {"rank": rank, "levels": [(tuple(l.layout.Ng), l.layout.slab is not None) for l in sim.pois.levels]}
     # static fields after construction
     for k in ("u", "mu0", "mu1", "V"):

@@ -78,9 +78,20 @@ def check(out, T):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,case", [(2, "sphere_f32"), (4, "sphere_long_f32"), (2, "donut_f64"), (2, "sphere_exit_f32")])
+@pytest.mark.parametrize("nproc,case", [(2, "sphere_deep_f32"), (4, "sphere_long_deep_f32"), (2, "donut_deep_f64"),
+                                        (2, "sphere_exit_deep_f32"), (2, "sphere_f32")])
 def test_slabs_match_undecomposed(nproc, case):
     out = run_workers("mg_worker.py", nproc, case)
-    # 32^3 on 2 ranks: levels 32,16,8 (16,8,4 planes per rank) are slabs, 4^3 and 2^3 are replicated
-    assert any(d for _, d in out["levels"]) and not out["levels"][-1][1]
+    # "deep", 32^3 on 2 ranks: levels 32,16,8 (16,8,4 planes per rank) are slabs, 4^3 and 2^3 are replicated;
+    # default: only the finest level is a slab (coarser ones hold <= 2^21 cells and are replicated)
+    nslab = sum(1 for _, d in out["levels"] if d)
+    assert (nslab >= 3 if "deep" in case else nslab == 1) and not out["levels"][-1][1]
     check(out, "f64" if case.endswith("f64") else "f32")
+
+
+@pytest.mark.gpu
+def test_rccl_bootstrap_world1():
+    """The RCCL communicator (unique-id broadcast through torch.distributed, ncclCommInitRank inside libwlhip)
+    comes up and a decomposed run works on it; only world size 1 is possible on a 1-GPU box."""
+    out = run_workers("mg_worker.py", 1, "sphere_rccl_f32")
+    check(out, "f32")

@@ -199,12 +199,14 @@ def gather(a: torch.Tensor) -> np.ndarray:
     """Assemble the undecomposed host array from the owned planes of every rank (tests / output)."""
     sl = getattr(a, "_wl_slab", None)
     h = to_host(a)
-    if sl is None or sl.size == 1:
+    if sl is None:
         return h
-    import torch.distributed as dist
     mine = np.ascontiguousarray(np.moveaxis(h, 2, 0)[sl.own_lo:sl.own_hi + 1])
-    parts = [None] * sl.size
-    dist.all_gather_object(parts, mine)
+    parts = [mine]
+    if sl.size > 1:
+        import torch.distributed as dist
+        parts = [None] * sl.size
+        dist.all_gather_object(parts, mine)
     return np.asfortranarray(np.moveaxis(np.concatenate(parts, axis=0), 0, 2))
 
 
@@ -394,7 +396,11 @@ class Poisson(_PoissonBase):
 class MultiLevelPoisson(_PoissonBase):
     """src/MultiLevelPoisson.jl:44-60"""
 
-    def __init__(self, x: torch.Tensor, L: torch.Tensor, z: torch.Tensor, maxlevels=10, perdir=(), padded=True):
+    def __init__(self, x: torch.Tensor, L: torch.Tensor, z: torch.Tensor, maxlevels=10, perdir=(), padded=True,
+                 replicate_cells=1 << 21):
+        """replicate_cells (multi-GPU only): levels with at most this many interior cells are replicated on every
+        rank instead of being z-slabs (their kernels are launch-latency bound, and a replicated level needs no
+        halo exchange and no all-reduce per dot product)."""
         assert x.shape == z.shape and tuple(L.shape) == tuple(x.shape) + (x.ndim,)
         self.T = _T(x)
         D = x.ndim
@@ -410,6 +416,8 @@ class MultiLevelPoisson(_PoissonBase):
         while _divisible(levels[-1].layout.Ng_global) and len(levels) <= maxlevels:
             Na = tuple(1 + n // 2 for n in levels[-1].layout.Ng_global)
             slab = slab.coarser() if slab is not None else None
+            if slab is not None and int(np.prod([n - 2 for n in Na])) <= replicate_cells:
+                slab = None
             la = Layout(Na, self.T, padded, slab)
             levels.append(_Level(la, la.alloc((), x.device), la.alloc((D,), x.device), la.alloc((), x.device), x.device))
         if len(levels) <= 2:
@@ -513,7 +521,8 @@ class Simulation:
     """src/WaterLily.jl:59-79"""
 
     def __init__(self, dims, u_BC, L, *, dt=0.25, nu=0.0, g=None, U=None, eps=1, perdir=(), ulam=None,
-                 exitBC=False, body=None, T=np.float32, device="cuda:0", padded=True, slab="auto"):
+                 exitBC=False, body=None, T=np.float32, device="cuda:0", padded=True, slab="auto",
+                 replicate_cells=1 << 21):
         assert not (callable(u_BC) and callable(ulam)), "`u_BC` and `uλ` cannot be both specified as Function"
         assert not (U is None and callable(u_BC)), "`U` must be specified if `u_BC` is a Function"
         if ulam is None:
@@ -530,7 +539,8 @@ class Simulation:
                          device=device, padded=padded, slab=slab)
         self._band = None
         measure_flow(self.flow, self.body, t=0.0, eps=eps)
-        self.pois = MultiLevelPoisson(self.flow.p, self.flow.mu0, self.flow.sigma, perdir=perdir, padded=padded)
+        self.pois = MultiLevelPoisson(self.flow.p, self.flow.mu0, self.flow.sigma, perdir=perdir, padded=padded,
+                                      replicate_cells=replicate_cells)
 
 
 def measure_flow(a: Flow, body, t=0.0, eps=1) -> None:
