@@ -189,6 +189,12 @@ int wl_mom_step(wl_flow *a, wl_mg *b, double dt, const double U[3], const double
 int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx_dev, const double *nds_dev,
               int64_t nband, double out[3]);
 
+/* ------------------------------------------------------------------ tuning switches (A/B measurements)
+ * key 0: 1 = use the 16-B-vectorised z-marching 7-point kernel where it applies (default), 0 = generic range kernel
+ * key 1: 1 = fused V-cycle smoothers (default), 0 = the reference's two-pass Jacobi!/increment!/prolongate!
+ * key 2: 1 = LDS-tiled marching conv_diff kernel (default), 0 = generic gather kernel */
+int wl_set_option(int key, int value);
+
 /* ------------------------------------------------------------------ measurement support */
 /* Kernel classes for launch counting and HIP-event timing (bench.py roofline leg). */
 enum {

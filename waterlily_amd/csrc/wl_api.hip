@@ -202,12 +202,14 @@ template <class T, int D> static int mg_update(wl_mg *m) {
     {
         LevelT<T> p = lvl<T>(m, 0);
         WL_TRY((op_set_diag<T, D>(p.g, p.D, p.iD, p.L)));
+        WL_TRY((halo_exchange<T>(p.g, p.iD, 1, 1)));   // z-slab: the fused smoother evaluates r*iD in the halo planes
     }
     for (int l = 1; l < m->nlev; ++l) {
         LevelT<T> a = lvl<T>(m, l), b = lvl<T>(m, l - 1);
         WL_TRY((op_restrictL<T, D>(a.g, a.L, b.g, b.L, m->permask)));
         WL_TRY((coarse_L_finish<T, D>(a.g, a.L, b.g, m->permask)));
         WL_TRY((op_set_diag<T, D>(a.g, a.D, a.iD, a.L)));
+        WL_TRY((halo_exchange<T>(a.g, a.iD, 1, 1)));
     }
     return 0;
 }
@@ -215,8 +217,10 @@ template <class T, int D> static int mg_update(wl_mg *m) {
 // Vcycle!  src/MultiLevelPoisson.jl:70-82
 template <class T, int D> static int mg_vcycle(wl_mg *m, int l) {
     LevelT<T> fine = lvl<T>(m, l), coarse = lvl<T>(m, l + 1);
-    WL_TRY((op_jacobi<T, D>(fine, 1, m->permask)));
-    WL_TRY((op_restrict<T, D>(coarse.g, coarse.r, fine.g, fine.r)));
+    const bool fused = (m->permask == 0) && ctx().opt[1];   // periodic ghosts of eps are copies, not zeros: keep the two-pass form
+    if (fused) WL_TRY((op_smooth_fused<T, D>(fine, fine.eps)));     // r' lives in the eps buffer until the way up
+    else WL_TRY((op_jacobi<T, D>(fine, 1, m->permask)));
+    WL_TRY((op_restrict<T, D>(coarse.g, coarse.r, fine.g, fused ? fine.eps : fine.r)));
     if (ctx().comm && ctx().comm->size > 1 && fine.g.dist && !coarse.g.dist) {
         // hand-over to the replicated coarse levels: every rank restricted the children it owns
         const int nzl = (fine.g.nzg - 2) / ctx().comm->size / 2;
@@ -228,6 +232,7 @@ template <class T, int D> static int mg_vcycle(wl_mg *m, int l) {
     }
     if (l + 2 < m->nlev) WL_TRY((mg_vcycle<T, D>(m, l + 1)));
     WL_TRY((op_pcg<T, D>(coarse, 6, m->permask, m->sc.partials, m->sc.st)));
+    if (fused) return op_prolong_increment_fused<T, D>(fine, fine.eps, coarse.g, coarse.x);
     WL_TRY((op_prolongate<T, D>(fine.g, fine.eps, coarse.g, coarse.x)));
     return op_increment<T, D>(fine, m->permask);
 }
@@ -668,6 +673,12 @@ int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx, c
         st->out[0] = v[0]; st->out[1] = v[1]; st->out[2] = v[2]; })));
     WL_TRY(S.fetch());
     for (int c = 0; c < g->D; ++c) out[c] = S.hst->out[c];
+    return 0;
+}
+
+int wl_set_option(int key, int value) {
+    if (key < 0 || key >= 8) return fail(WL_E_ARG, "wl_set_option: bad key", __FILE__, __LINE__);
+    ctx().opt[key] = value;
     return 0;
 }
 

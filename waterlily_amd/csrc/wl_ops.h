@@ -8,6 +8,7 @@
 #pragma once
 #include "wl_common.h"
 #include "wl_convdiff.h"
+#include "wl_stencil7.h"
 
 namespace wl {
 
@@ -210,7 +211,7 @@ template <class T, int D, bool FUSE>
 int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T *u0, const T *V, double dt_,
                  const double *acc, bool has_acc) {
     if constexpr (D == 3) {
-        if (permask == 0 && g.n[0] >= 5 && g.n[1] >= 5 && g.n[2] >= 5) {
+        if (ctx().opt[2] && permask == 0 && g.n[0] >= 5 && g.n[1] >= 5 && g.n[2] >= 5) {
             WL_TRY((launch_convdiff3<T, FUSE>(g, r, u, nu_, u0, V, dt_, acc, has_acc)));
             Range R0 = r_whole(g), R1 = r_whole(g);
             R0.hi[0] = 0;
@@ -395,6 +396,24 @@ int op_residual(const LevelT<T> &p, int permask, double *partials, State *st) {
     WL_TRY((op_bc_per<T, D>(p.g, p.x, permask)));
     const LevelT<T> q = p;
     int np = 0;
+    int rcv = -1;
+    if constexpr (D == 3) {
+        if (stencil7_ok<T>(p.g, p.x, p.L) && stencil7_ok<T>(p.g, p.r, p.iD) && stencil7_ok<T>(p.g, p.z, p.L)) {
+            using VA = VecA<T>;
+            rcv = launch_stencil7<T, 1>(WL_K_RESIDUAL, p.g, SrcArray<T>{p.x}, p.L, [=] __device__(long o, const VA &ax, const VA &, double *acc) {
+                const VA id = VA::load(q.iD + o), zz = VA::load(q.z + o);
+                VA rv;
+_Pragma("unroll")
+                for (int v = 0; v < VA::V; ++v) {
+                    rv.v[v] = (id.v[v] == 0) ? (T)0 : zz.v[v] - ax.v[v];
+                    acc[0] += (double)rv.v[v];
+                }
+                rv.store(q.r + o);
+            }, partials, &np);
+            if (rcv > 0) return rcv;
+        }
+    }
+    if (rcv != 0)
     WL_TRY((launch_range_red<1>(WL_K_RESIDUAL, r_inside(p.g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
         const long I = q.g.at(i, j, k);
         const T v = (q.iD[I] == 0) ? (T)0 : q.z[I] - mult1r<T, D>(q.g, q.L, q.x, I);
@@ -420,6 +439,19 @@ template <class T, int D>
 int op_increment(const LevelT<T> &p, int permask) {
     WL_TRY((op_bc_per<T, D>(p.g, p.eps, permask)));
     const LevelT<T> q = p;
+    if constexpr (D == 3) {
+        if (stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.r, p.x)) {
+            using VA = VecA<T>;
+            const int rcv = launch_stencil7<T, 0>(WL_K_INCREMENT, p.g, SrcArray<T>{p.eps}, p.L, [=] __device__(long o, const VA &ae, const VA &ec, double *) {
+                VA rv = VA::load(q.r + o), xv = VA::load(q.x + o);
+_Pragma("unroll")
+                for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
+                rv.store(q.r + o);
+                xv.store(q.x + o);
+            }, nullptr, nullptr);
+            if (rcv >= 0) return rcv;
+        }
+    }
     return launch_range(WL_K_INCREMENT, r_inside(p.g), [=] __device__(int i, int j, int k) {
         const long I = q.g.at(i, j, k);
         q.r[I] = q.r[I] - mult1r<T, D>(q.g, q.L, q.eps, I);
@@ -439,6 +471,96 @@ int op_jacobi(const LevelT<T> &p, int it, int permask) {
         WL_TRY((op_increment<T, D>(p, permask)));
     }
     return 0;
+}
+
+// ---- fused V-cycle smoothers (non-periodic grids; used by Vcycle! only, the stand-alone operators stay as above)
+// Jacobi!(it=1) = [eps = r*iD ; r -= A eps ; x += eps]  (src/Poisson.jl:110-113,99-103) in ONE pass: eps is
+// evaluated on the fly at the 7 stencil points (ghost eps is 0 because ghost r and iD are 0), the new residual
+// goes OUT OF PLACE into `rout` (the eps buffer, whose content is dead inside Vcycle!), so neighbours still
+// read the old r: no race, eps is never written.  Same per-cell operations => same bits as the two-pass form.
+template <class T, int D>
+int op_smooth_fused(const LevelT<T> &p, T *rout) {
+    WL_TRY((halo_exchange<T>(p.g, p.r, 1, 1)));   // z-slab runs: eps at halo cells = r*iD of the neighbour rank
+    const LevelT<T> q = p;
+    if constexpr (D == 3) {
+        if (stencil7_ok<T>(p.g, p.r, p.L) && stencil7_ok<T>(p.g, p.iD, p.x) && stencil7_ok<T>(p.g, rout, p.L)) {
+            using VA = VecA<T>;
+            const int rcv = launch_stencil7<T, 0>(WL_K_SMOOTH, p.g, SrcJacobi<T>{p.r, p.iD}, p.L,
+                [=] __device__(long o, const VA &ae, const VA &ec, double *) {
+                    VA rv = VA::load(q.r + o), xv = VA::load(q.x + o);
+_Pragma("unroll")
+                    for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
+                    rv.store(rout + o);
+                    xv.store(q.x + o);
+                }, nullptr, nullptr);
+            if (rcv >= 0) return rcv;
+        }
+    }
+    return launch_range(WL_K_SMOOTH, r_inside(p.g), [=] __device__(int i, int j, int k) {
+        const long I = q.g.at(i, j, k);
+        T lo[D], hi[D];
+_Pragma("unroll")
+        for (int d = 0; d < D; ++d) { lo[d] = q.L[I + (long)d * q.g.sc]; hi[d] = q.L[I + q.g.s[d] + (long)d * q.g.sc]; }
+        T dg = 0;
+_Pragma("unroll")
+        for (int d = 0; d < D; ++d) dg -= (lo[d] + hi[d]);
+        const T e0 = q.r[I] * q.iD[I];
+        T s = e0 * dg;
+_Pragma("unroll")
+        for (int d = 0; d < D; ++d) {
+            const long sd = q.g.s[d];
+            s += (q.r[I - sd] * q.iD[I - sd]) * lo[d] + (q.r[I + sd] * q.iD[I + sd]) * hi[d];
+        }
+        rout[I] = q.r[I] - s;
+        q.x[I] = q.x[I] + e0;
+    });
+}
+// prolongate!(fine.eps, coarse.x) ; increment!(fine)  (src/MultiLevelPoisson.jl:80-81) in ONE pass: eps at a
+// fine cell is the coarse x of its parent (down(I), :2), 0 on ghost cells; residual read from `rin`, written to
+// p.r (the pair of fused kernels moves r: R -> E -> R, so the buffers end up in their own roles).
+template <class T, int D>
+int op_prolong_increment_fused(const LevelT<T> &p, const T *rin, const G &gc, const T *cx) {
+    WL_TRY((halo_exchange<T>(gc, const_cast<T *>(cx), 1, 1)));   // z-slab coarse level: parents in the halo plane
+    const LevelT<T> q = p;
+    const G C = gc;
+    if constexpr (D == 3) {
+        if (stencil7_ok<T>(p.g, p.r, p.L) && stencil7_ok<T>(p.g, rin, p.x)) {
+            using VA = VecA<T>;
+            const SrcProlong<T> src{cx, C, p.g.n[0], p.g.n[1], p.g.nzg, p.g.kz0};
+            const int rcv = launch_stencil7<T, 0>(WL_K_SMOOTH, p.g, src, p.L,
+                [=] __device__(long o, const VA &ae, const VA &ec, double *) {
+                    VA rv = VA::load(rin + o), xv = VA::load(q.x + o);
+_Pragma("unroll")
+                    for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
+                    rv.store(q.r + o);
+                    xv.store(q.x + o);
+                }, nullptr, nullptr);
+            if (rcv >= 0) return rcv;
+        }
+    }
+    return launch_range(WL_K_SMOOTH, r_inside(p.g), [=] __device__(int i, int j, int k) {
+        const long I = q.g.at(i, j, k);
+        const int gi[3] = {i, j, D > 2 ? q.g.kg(k) : 0};          // global fine index
+        const int ng[3] = {q.g.n[0], q.g.n[1], q.g.nzg};
+        auto epsat = [&](int d, int off) -> T {                    // eps at the neighbour `off` along d
+            int f[3] = {gi[0], gi[1], gi[2]};
+            f[d] += off;
+            if (f[d] < 1 || f[d] > ng[d] - 2) return (T)0;         // ghost cell of the undecomposed array
+            return cx[C.at((f[0] + 1) / 2, (f[1] + 1) / 2, D > 2 ? (f[2] + 1) / 2 - C.kz0 : 0)];
+        };
+        T lo[D], hi[D];
+_Pragma("unroll")
+        for (int d = 0; d < D; ++d) { lo[d] = q.L[I + (long)d * q.g.sc]; hi[d] = q.L[I + q.g.s[d] + (long)d * q.g.sc]; }
+        T dg = 0;
+_Pragma("unroll")
+        for (int d = 0; d < D; ++d) dg -= (lo[d] + hi[d]);
+        const T e0 = epsat(0, 0);
+        T s = e0 * dg;
+_Pragma("unroll")
+        for (int d = 0; d < D; ++d) s += epsat(d, -1) * lo[d] + epsat(d, +1) * hi[d];
+        q.r[I] = rin[I] - s;
+        q.x[I] = q.x[I] + e0;
+    });
 }
 
 // pcg!  src/Poisson.jl:123-143 with device-resident rho/alpha/beta and the four early exits turned into a
@@ -466,6 +588,20 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st)
     for (int n = 1; n <= it; ++n) {
         WL_TRY((op_bc_per<T, D>(p.g, p.eps, permask)));  // :129 (no-op unless periodic)
         // :130-131
+        int rcv = -1;
+        if constexpr (D == 3) {
+            if (stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.z, p.L)) {
+                using VA = VecA<T>;
+                rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g, SrcArray<T>{p.eps}, p.L, [=] __device__(long o, const VA &ae, const VA &ec, double *acc) {
+                    if (!st->active) return;
+                    ae.store(q.z + o);
+_Pragma("unroll")
+                    for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];
+                }, partials, &np);
+                if (rcv > 0) return rcv;
+            }
+        }
+        if (rcv != 0)
         WL_TRY((launch_range_red<1>(WL_K_PCG_MULT, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
             if (!st->active) return;
             const long I = q.g.at(i, j, k);

@@ -355,6 +355,9 @@ def _layout_of(x: torch.Tensor) -> Layout:
     lay.s = (1, st[1], st[2] if D == 3 else st[1] * n[1])
     lay.span = lay.s[2] * n[2]
     lay.sc = lay.span
+    # keep the alignment rule of the fields we were given: first interior element of a row on a 128-B boundary
+    if (x.data_ptr() + x.element_size()) % 128 == 0:
+        lay.lead = lay.align - 1
     return lay
 
 
