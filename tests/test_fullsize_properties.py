@@ -1,0 +1,115 @@
+"""Size-independent properties checked at a BASELINE size (256^3 Float32 = configs[1]; WL_FULLSIZE=512 runs the same
+checks at the 512^3 headline size), where the CPU oracle is too slow to be the checker:
+
+  * BC! is idempotent;  conv_diff! of a uniform stream is exactly zero on inside cells;
+  * A is symmetric: x.(Ay) == y.(Ax);  mult! is exactly linear under power-of-two scaling;
+  * restrict!(prolongate!(c)) == 8c (to the rounding of the partial sums);  restrict! conserves the sum;
+  * solver! leaves r.r < tol and the projected velocity divergence-free to that tolerance;
+  * an impulsively started uniform stream stays uniform (maintests.jl:172-180 at scale);
+  * hydrostatic pressure_force on a sphere = its volume (maintests.jl:341-346 in 3-D)."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N = int(os.environ.get("WL_FULLSIZE", "256"))
+T = np.float32
+
+
+@pytest.fixture(scope="module")
+def S():
+    from waterlily_amd import sim
+    return sim
+
+
+@pytest.fixture(scope="module")
+def flow(S):
+    U = (2 / 3, -1 / 3, 0.25)
+    a = S.Flow((N, N, N), U, T=T, ulam=lambda i, x: U[i])
+    return a, S.MultiLevelPoisson(a.p, a.mu0, a.sigma), U
+
+
+def rand_like(a, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.rand(a.shape, generator=g, device="cuda", dtype=a.dtype) - 0.5
+
+
+def test_bc_idempotent_and_uniform_convdiff_zero(S, flow):
+    a, ml, U = flow
+    u1 = a.u.clone()
+    S.BC(a.u, U)
+    assert torch.equal(a.u, u1)
+    S.conv_diff(a.f, a.u, nu=0.01)
+    # (the two x-planes next to the exit are excluded: the Flow constructor's exitBC! (Flow.jl:115) shifts the exit
+    #  plane by the rounding of its mean-flux correction)
+    inner = (slice(1, -3),) + (slice(1, -1),) * 2
+    assert float(a.f[inner].abs().max()) == 0.0
+
+
+def test_operator_symmetry_and_linearity(S, flow):
+    a, ml, U = flow
+    lv = ml.levels[0]
+    x, y = lv.layout.alloc((), "cuda:0"), lv.layout.alloc((), "cuda:0")
+    inner = (slice(1, -1),) * 3
+    x[inner] = rand_like(x[inner], 1)
+    y[inner] = rand_like(y[inner], 2)
+    Ay = S.copy_of(S.mult(ml, y))
+    xAy = S.dot(x, Ay)
+    Ax = S.copy_of(S.mult(ml, x))
+    yAx = S.dot(y, Ax)
+    assert abs(xAy - yAx) <= 1e-5 * max(abs(xAy), 1.0)
+    x4 = S.like(x)
+    x4[inner] = x[inner] * 4
+    A4x = S.mult(ml, x4)
+    assert torch.equal(A4x[inner], Ax[inner] * 4)
+
+
+def test_restrict_prolongate_identities(S, flow):
+    a, ml, U = flow
+    f, c = ml.levels[0], ml.levels[1]
+    ci = (slice(1, -1),) * 3
+    c.x.zero_()
+    c.x[ci] = rand_like(c.x[ci], 3)
+    S.prolongate(f.eps, c.x)
+    S.restrict(c.r, f.eps)
+    # sum of the 8 identical children: 8c up to the roundings of the partial sums 3c,5c,6c,7c
+    assert float((c.r[ci] - 8 * c.x[ci]).abs().max()) <= 4 * np.finfo(T).eps * 8 * float(c.x[ci].abs().max())
+    f.r.zero_()
+    f.r[ci] = rand_like(f.r[ci], 4)
+    S.restrict(c.r, f.r)
+    sf, sc = float(f.r.double().sum()), float(c.r.double().sum())
+    assert abs(sf - sc) <= 1e-6 * max(1.0, float(f.r.double().abs().sum()))
+
+
+def test_projection_divergence_free_and_uniform_stream(S, flow):
+    a, ml, U = flow
+    S.mom_step(a, ml)
+    assert all(1 <= n <= 32 for n in ml.n[-2:])
+    assert S.L2p(ml) < 1e-4                                   # solver! tolerance (MultiLevelPoisson.jl:87,95)
+    z = S.like(a.p)
+    S.divergence(z, a.u)
+    assert S.L2(z) < 1e-3
+    for i in range(3):                                        # impulsive uniform stream stays uniform
+        d = (a.u[..., i] - U[i])[(slice(1, -1),) * 3]
+        assert float((d.double() ** 2).sum()) < 2e-5 * (N / 16) ** 3
+
+
+def test_hydrostatic_force_on_sphere(S):
+    from waterlily_amd import body as B
+    from waterlily_amd.body import AutoBody, norm2
+    n = min(N, 128)                                            # the band search is host-side: keep it short
+    R, c = n / 4, n / 2
+    body = AutoBody(lambda x, t: norm2(x - c) - R)
+    lay = S.Layout((n + 2,) * 3, T, True)
+    p = lay.alloc((), "cuda:0")
+    yy = torch.arange(n + 2, device="cuda", dtype=torch.float32) - 0.5
+    p.copy_(yy[None, :, None].expand(n + 2, n + 2, n + 2))
+    idx, nds = B.nds_band(body, (n, n, n))
+    force = S.pressure_force_band(p, *S.band_to_device(p, idx, nds))
+    vol = 4 / 3 * math.pi * R ** 3
+    assert np.sum(np.abs(force / vol - np.array([0, 1, 0]))) < 2e-3

@@ -118,6 +118,47 @@ def _ptr(a: torch.Tensor) -> C.c_void_p:
     return C.c_void_p(a.data_ptr())
 
 
+def like(a: torch.Tensor, fill: float = 0.0) -> torch.Tensor:
+    """A new field with the SAME strides and row alignment as `a` (torch's .clone() would return a dense tensor,
+    which must never be handed to the library together with `a`'s grid)."""
+    item = a.element_size()
+    al = 128 // item
+    lead = (a.data_ptr() // item) % al
+    need = 1 + sum((n - 1) * st for n, st in zip(a.shape, a.stride()))
+    buf = torch.full((lead + need + al,), fill, dtype=a.dtype, device=a.device)
+    out = torch.as_strided(buf, a.size(), a.stride(), lead)
+    out._wl_slab = getattr(a, "_wl_slab", None)
+    return out
+
+
+def copy_of(a: torch.Tensor) -> torch.Tensor:
+    b = like(a)
+    b.copy_(a)
+    return b
+
+
+def _same_layout(a: torch.Tensor, b: torch.Tensor) -> None:
+    if a.shape != b.shape or a.stride() != b.stride() or a.dtype != b.dtype:
+        raise ValueError("fields must share shape, strides and dtype (use waterlily_amd.sim.like/copy_of, not .clone())")
+
+
+def dot(a: torch.Tensor, b: torch.Tensor) -> float:
+    """LinearAlgebra.dot over inside(a) (src/Poisson.jl:126-146)"""
+    _same_layout(a, b)
+    out = C.c_double()
+    g = _grid_of(a, a.ndim)
+    check(_lib.lib().wl_dot(_WLT[_T(a)], C.byref(g), _ptr(a), _ptr(b), C.byref(out)))
+    return out.value
+
+
+def divergence(z: torch.Tensor, u: torch.Tensor) -> None:
+    """@inside z[I] = div(I,u)  (src/Flow.jl:139)"""
+    if tuple(u.shape[:-1]) != tuple(z.shape) or u.stride()[:-1] != z.stride():
+        raise ValueError("z and u must share the grid layout")
+    g = _grid_of(z, z.ndim)
+    check(_lib.lib().wl_div(_WLT[_T(z)], C.byref(g), _ptr(z), _ptr(u)))
+
+
 def to_host(a: torch.Tensor) -> np.ndarray:
     """`Array(field)`: dense Fortran-ordered host copy."""
     return np.asfortranarray(a.detach().cpu().numpy())
@@ -212,6 +253,7 @@ def gather(a: torch.Tensor) -> np.ndarray:
 
 def exitBC(u: torch.Tensor, u0: torch.Tensor, U, dt: float) -> None:
     """util.jl:216-222"""
+    _same_layout(u, u0)
     g = _grid_of(u, u.ndim - 1)
     check(_lib.lib().wl_exit_bc(_WLT[_T(u)], C.byref(g), _ptr(u), _ptr(u0), d3(U), float(dt)))
 
@@ -297,6 +339,7 @@ def time(a: Flow) -> float:
 
 def conv_diff(r: torch.Tensor, u: torch.Tensor, Phi=None, nu=0.1, perdir=()):
     """Flow.jl:36-51 (Phi is accepted for signature parity; the gather kernel needs no scratch)."""
+    _same_layout(r, u)
     g = _grid_of(u, u.ndim - 1)
     check(_lib.lib().wl_conv_diff(_WLT[_T(u)], C.byref(g), _ptr(r), _ptr(u), float(nu), permask(perdir)))
 
