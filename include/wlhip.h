@@ -173,6 +173,11 @@ typedef struct wl_flow wl_flow; /* opaque */
 
 int wl_flow_create(wl_flow **out, wl_dtype t, const wl_flow_desc *desc);
 int wl_flow_destroy(wl_flow *a);
+/* Must be called after the coefficient fields mu0, mu1, V were (re)written -- i.e. at the end of measure!(flow,body)
+ * (src/Body.jl:31-53), next to update!(pois).  It rebuilds the per-row "body-free" flags (mu1 == 0, V == 0,
+ * mu0 == 1 on a whole x-row) that let BDIM! skip those 15 coefficient reads where they are known constants; results
+ * are identical with or without the flags.  Until the first call every row takes the general path. */
+int wl_flow_update(wl_flow *a);
 /* project!(a,b,w)                     src/Flow.jl:137-145 */
 int wl_project(wl_flow *a, wl_mg *b, double dt, double w, int *n_iter);
 /* mom_step!(a,b)                      src/Flow.jl:153-169.  dt = a.dt[end]; U = BCTuple(a.U,a.dt,N);
@@ -192,7 +197,8 @@ int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx_de
 /* ------------------------------------------------------------------ tuning switches (A/B measurements)
  * key 0: 1 = use the 16-B-vectorised z-marching 7-point kernel where it applies (default), 0 = generic range kernel
  * key 1: 1 = fused V-cycle smoothers (default), 0 = the reference's two-pass Jacobi!/increment!/prolongate!
- * key 2: 1 = LDS-tiled marching conv_diff kernel (default), 0 = generic gather kernel */
+ * key 2: 1 = LDS-tiled marching conv_diff kernel (default), 0 = generic gather kernel
+ * key 3: 1 = BDIM! uses the body-free row flags (default), 0 = general path everywhere */
 int wl_set_option(int key, int value);
 
 /* ------------------------------------------------------------------ measurement support */

@@ -26,9 +26,16 @@ LAMBDA = {  # (operator, kernel kind, lambda ordinal) -> libwlhip kernel class
 }
 
 
+S7 = {"op_pcg": "pcg_mult_dot", "op_increment": "increment", "op_residual": "residual", "op_smooth_fused": "smooth",
+      "op_prolong_increment_fused": "smooth_prolong"}
+
+
 def classify(name):
     if "k_convdiff3" in name:
         return "conv_diff"
+    if "k_stencil7" in name:
+        m = re.search(r"(op_\w+?)<", name)
+        return S7.get(m.group(1)) if m else None
     m = re.search(r"(k_range_red|k_range)<.*?(op_\w+?)<", name)
     o = re.search(r"#(\d)\}", name)
     if not m or not o:

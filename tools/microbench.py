@@ -55,3 +55,17 @@ ab("pcg mult+dot (6T)", "pcg_mult_dot", 0, lambda: S.pcg(ml), 6)
 ab("increment (9T)", "increment", 0, lambda: S.increment(ml), 9)
 ab("residual (8T)", "residual", 0, lambda: S.residual(ml), 8)
 ab("V-cycle smoother (9T)", "smooth", 1, lambda: S.Vcycle(ml), 9)
+
+# BDIM! inside mom_step (option 3 = body-free row flags): needs a body
+import bench  # noqa: E402
+sim = bench.sphere((size,) * 3, T)
+for val in (1, 0, 1, 0):
+    _lib.check(L.wl_set_option(3, val))
+    t, n = timed("bdim", lambda: S.sim_step(sim, remeasure=False))
+    print(f"BDIM!#2 in mom_step          option[3]={val}: {t:7.3f} ms/launch ({n} launches)")
+_lib.check(L.wl_set_option(3, 1))
+for val in (1, 0, 1, 0):
+    _lib.check(L.wl_set_option(2, val))
+    t, n = timed("conv_diff", lambda: S.sim_step(sim, remeasure=False))
+    print(f"conv_diff!+BDIM!#1           option[2]={val}: {t:7.3f} ms/launch ({n} launches)")
+_lib.check(L.wl_set_option(2, 1))

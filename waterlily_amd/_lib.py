@@ -119,6 +119,7 @@ def lib() -> C.CDLL:
         "wl_mg_solve": (i, [vp, d, i, ip]),
         "wl_flow_create": (i, [C.POINTER(vp), i, C.POINTER(FlowDesc)]),
         "wl_flow_destroy": (i, [vp]),
+        "wl_flow_update": (i, [vp]),
         "wl_project": (i, [vp, vp, d, d, ip]),
         "wl_mom_step": (i, [vp, vp, d, dp, dp, dp, dp, ip]),
         "wl_pforce": (i, [i, gp, vp, vp, vp, i64, dp]),

@@ -187,6 +187,8 @@ struct wl_flow {
     wl_dtype t;
     wl_flow_desc d;
     Scratch sc;
+    unsigned char *rowfree = nullptr;   // body-free row flags (wl_flow_update); nullptr until built
+    unsigned char *rowbuf = nullptr;
 };
 
 template <class T> static LevelT<T> lvl(const wl_mg *m, int l) {
@@ -285,7 +287,7 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     // (z-slab runs: u carries a 2-plane halo for QUICK, f a 1-plane halo for mu_ddn; exchanges are no-ops otherwise)
     WL_TRY((op_conv_diff<T, D, true>(g, f, u0, d.nu, d.perdir_mask, u0, V, dt, gp, gp != nullptr)));
     WL_TRY((halo_exchange<T>(g, f, D, 1)));
-    WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1)));
+    WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, u, u0, U, dt, a->sc.partials, a->sc.st)));
     WL_TRY((halo_exchange<T>(g, u, D, 1)));
@@ -295,7 +297,7 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     // corrector (:164-167)
     WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr)));
     WL_TRY((halo_exchange<T>(g, f, D, 1)));
-    WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1)));
+    WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     WL_TRY((halo_exchange<T>(g, u, D, 1)));
     WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1])));
@@ -338,6 +340,12 @@ __global__ __launch_bounds__(256) void k_pforce(const T *p, const int64_t *idx, 
     block_red<3>(acc, RED_SUM);
     if (threadIdx.x == 0)
         for (int c = 0; c < 3; ++c) partials[(long)c * gridDim.x + blockIdx.x] = acc[c];
+}
+template <class T, int D> static int flow_update(wl_flow *a) {
+    const G g = mkG(&a->d.g);
+    WL_TRY((op_rowflags<T, D>(g, (const T *)a->d.V, (const T *)a->d.mu0, (const T *)a->d.mu1, a->rowbuf, a->d.perdir_mask)));
+    a->rowfree = a->rowbuf;
+    return 0;
 }
 template <class T, int D> static int restrictL_full(const G &A, T *a, const G &B, const T *b, int permask) {
     WL_TRY((op_restrictL<T, D>(A, a, B, b, permask)));
@@ -619,6 +627,8 @@ int wl_flow_create(wl_flow **out, wl_dtype t, const wl_flow_desc *d) {
     a->t = t; a->d = *d;
     int rc = a->sc.init();
     if (rc) { delete a; return rc; }
+    const size_t nrows = (size_t)d->g.n[1] * (size_t)(d->g.D > 2 ? d->g.n[2] : 1);
+    if (hipMalloc((void **)&a->rowbuf, nrows) != hipSuccess) { a->sc.release(); delete a; return fail(WL_E_STATE, "hipMalloc(row flags)", __FILE__, __LINE__); }
     *out = a;
     return 0;
 }
@@ -626,8 +636,13 @@ int wl_flow_destroy(wl_flow *a) {
     if (!a) return 0;
     (void)hipStreamSynchronize(ctx().stream);
     a->sc.release();
+    if (a->rowbuf) (void)hipFree(a->rowbuf);
     delete a;
     return 0;
+}
+int wl_flow_update(wl_flow *a) {
+    if (!a) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);
+    WL_DISPATCH(a->t, a->d.g.D, (flow_update<T, DD>(a)));
 }
 static int check_pair(const wl_flow *a, const wl_mg *b) {
     if (!a || !b) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);

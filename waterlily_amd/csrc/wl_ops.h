@@ -255,11 +255,24 @@ _Pragma("unroll")
 // second BDIM! loop  src/Flow.jl:134 with mu_ddn (:18-24).  MODE 0: u += ...  (the reference statement)
 // MODE 1: predictor, u was zeroed by scale_u!(a,0) (:154) -> u = ... ; MODE 2: corrector, followed by
 // scale_u!(a,0.5) (:166) -> u = 0.5*(u + ...), both roundings kept.
+// `rowfree` (optional, mom_step! only): rowfree[j + n1*k] != 0 means mu1 == 0, V == 0 and mu0 == 1 on x-row (j,k), so
+// the statement reduces to u (+)= f -- same value, 15 coefficient reads and 6 neighbour reads per cell skipped.
 template <class T, int D, int MODE>
-int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu1) {
+int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu1, const unsigned char *rowfree = nullptr) {
     const G gg = g;
+    if (!ctx().opt[3]) rowfree = nullptr;
     return launch_range(WL_K_BDIM, r_inside(g), [=] __device__(int i, int j, int k) {
         const long I = gg.at(i, j, k);
+        if (rowfree && rowfree[j + gg.n[1] * k]) {   // wave-uniform: a wavefront never spans two rows
+_Pragma("unroll")
+            for (int c = 0; c < D; ++c) {
+                const long q = I + (long)c * gg.sc;
+                const double tmp = (0.5 * 0.0 + 0.0) + (double)f[q];
+                if (MODE == 1) u[q] = (T)(0.0 + tmp);
+                else { const T un = (T)((double)u[q] + tmp); u[q] = (MODE == 2) ? (T)((double)un * 0.5) : un; }
+            }
+            return;
+        }
 _Pragma("unroll")
         for (int c = 0; c < D; ++c) {
             const T *fc = f + (long)c * gg.sc;
@@ -279,6 +292,39 @@ _Pragma("unroll")
             }
         }
     });
+}
+
+// body-free row flags (see op_bdim2): one wavefront scans one x-row of the 15 coefficient arrays
+template <class T, int D>
+__global__ __launch_bounds__(256) void k_rowflags(G g, const T *V, const T *mu0, const T *mu1, unsigned char *flags, bool xper) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nrows = (long)g.n[1] * (D > 2 ? g.n[2] : 1);
+    if (row >= nrows) return;
+    const int j = (int)(row % g.n[1]), k = (int)(row / g.n[1]);
+    const long base = g.at(0, j, k);
+    bool busy = false;
+    // interior cells only (BDIM! does not touch ghosts).  With a non-periodic x the inflow face (i=1, component x)
+    // carries the zero of BC!(mu0,0) (Flow.jl:119) in EVERY row; inside mom_step! the BC!(u) that follows BDIM!
+    // (Flow.jl:159,166) overwrites u_x on that plane, so its mu0 is not allowed to mark the row busy.
+    for (int i = 1 + lane; i <= g.n[0] - 2; i += 64) {
+        const long I = base + i;
+        for (int c = 0; c < D; ++c) {
+            const bool inflow_face = (i == 1 && c == 0 && !xper);
+            busy = busy || (V[I + (long)c * g.sc] != (T)0) || (!inflow_face && mu0[I + (long)c * g.sc] != (T)1);
+            for (int d = 0; d < D; ++d) busy = busy || (mu1[I + (long)(c + D * d) * g.sc] != (T)0);
+        }
+    }
+    const unsigned long long any = __ballot(busy);
+    if (lane == 0) flags[j + (long)g.n[1] * k] = any ? 0 : 1;
+}
+template <class T, int D>
+int op_rowflags(const G &g, const T *V, const T *mu0, const T *mu1, unsigned char *flags, int permask) {
+    const long nrows = (long)g.n[1] * (D > 2 ? g.n[2] : 1);
+    Prof p(WL_K_MISC, g.cells());
+    hipLaunchKernelGGL((k_rowflags<T, D>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ctx().stream, g, V, mu0, mu1, flags,
+                       (bool)(permask & 1));
+    return (int)hipGetLastError();
 }
 
 // scale_u!  src/Flow.jl:170

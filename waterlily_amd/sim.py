@@ -593,6 +593,7 @@ def measure_flow(a: Flow, body, t=0.0, eps=1) -> None:
     """Body.jl:31-53: the user's sdf/map closures run on the host (body.measure_fields); the coefficient
     fields are uploaded and the two BC! calls run on the device."""
     if isinstance(body, B.NoBody):
+        flow_update(a)
         return
     mu0, mu1, V, d = B.measure_fields(body, tuple(n - 2 for n in a.N), t=t, eps=eps, T=a.T, slab=a.slab)
     upload(a.mu0, mu0)
@@ -603,6 +604,12 @@ def measure_flow(a: Flow, body, t=0.0, eps=1) -> None:
     BC(a.V, (0.0,) * a.D, a.exitBC, a.perdir)
     halo_exchange(a.mu0, 2)   # (mu1 needs no exchange: the host evaluated the halo planes from the sdf directly)
     halo_exchange(a.V, 2)
+    flow_update(a)
+
+
+def flow_update(a: Flow) -> None:
+    """Tell the library that mu0/mu1/V changed (rebuilds BDIM!'s body-free row flags); measure! does it."""
+    check(_lib.lib().wl_flow_update(a._h))
 
 
 def sim_time(sim: Simulation) -> float:
