@@ -202,7 +202,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"3D sphere {dims[0]}x{dims[1]}x{dims[2]}, Re=3700, {args.dtype}, uniform inflow, "
-                               f"remeasure=false" + (" (BASELINE configs[2])" if world == 1 and not args.grid else
+                               f"remeasure=false" + (" (BASELINE configs[2])" if world == 1 and not args.grid and m == 512
+                                                     and args.dtype == "f32" else "" if world == 1 else
                                                      f", z-slabs over {world} GPUs (RCCL halo exchange)"),
                    "vcycles_per_solve": vcycles[:6], "mean_vcycles_per_step": float(np.sum(vcycles)) / args.steps},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -279,13 +279,11 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     const G g = mkG(&d.g);
     T *u = (T *)d.u, *u0 = (T *)d.u0, *f = (T *)d.f, *V = (T *)d.V, *mu0 = (T *)d.mu0, *mu1 = (T *)d.mu1;
     const size_t vbytes = (size_t)((long)(D - 1) * g.sc + span(g)) * sizeof(T);
-    {   // a.u0 .= a.u (:154); scale_u!(a,0) is folded into the predictor BDIM (MODE 1)
-        Prof p(WL_K_COPY, g.cells() * D);
-        WL_HIP(hipMemcpyAsync(u0, u, vbytes, hipMemcpyDeviceToDevice, ctx().stream));
-    }
-    // predictor (:157-161): conv_diff! + accelerate! + BDIM! #1 fused, then BDIM! #2
+    (void)vbytes;
+    // predictor (:157-161): a.u0 .= a.u (:154) + conv_diff! + accelerate! + BDIM! #1 in ONE kernel (it reads u, writes
+    // u0 and f); scale_u!(a,0) is folded into the predictor BDIM #2 (MODE 1).
     // (z-slab runs: u carries a 2-plane halo for QUICK, f a 1-plane halo for mu_ddn; exchanges are no-ops otherwise)
-    WL_TRY((op_conv_diff<T, D, true>(g, f, u0, d.nu, d.perdir_mask, u0, V, dt, gp, gp != nullptr)));
+    WL_TRY((op_conv_diff<T, D, true, true>(g, f, u, d.nu, d.perdir_mask, nullptr, V, dt, gp, gp != nullptr, u0)));
     WL_TRY((halo_exchange<T>(g, f, D, 1)));
     WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));

@@ -47,9 +47,11 @@ template <class T> __device__ __forceinline__ T cd_sub(T r, double F, bool bnd) 
     return bnd ? (T)((double)r - F) : r - (T)F;
 }
 
-template <class T, bool FUSE>
+// COPY (predictor, Flow.jl:154): `a.u0 .= a.u` is folded in -- the kernel reads u, writes u0out = u for every cell it
+// owns and uses that value in the BDIM epilogue (saves the separate 6T copy pass).
+template <class T, bool FUSE, bool COPY>
 __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__ r, const T *__restrict__ u, T nu,
-                                                           const T *__restrict__ u0, const T *__restrict__ V, T dt,
+                                                           const T *u0, T *u0out, const T *__restrict__ V, T dt,
                                                            double a0, double a1, double a2, bool has_acc, int ntx,
                                                            int tpp, int nblk, int clen) {
     __shared__ T sm[3][3][CD_R][CD_W];  // [plane slot][component][row][col]
@@ -123,7 +125,8 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
             nxt[c] = u[col + sz * kn + sc * c];
 #pragma unroll
             for (int q = 0; q < 2; ++q) if (q < nh) hv[q][c] = u[hg[q] + sz * kh + sc * c];
-            if (FUSE) { e0[c] = u0[col + sz * k + sc * c]; eV[c] = V[col + sz * k + sc * c]; }
+            if (FUSE) { e0[c] = COPY ? W[c][2] : u0[col + sz * k + sc * c]; eV[c] = V[col + sz * k + sc * c]; }
+            if (COPY && own && active) u0out[col + sz * k + sc * c] = W[c][2];
         }
         // ---- B. fluxes of plane k
         const int s1 = (k + 3) % 3, s0 = (k + 2) % 3;  // LDS slots of planes k and k-1
@@ -215,9 +218,9 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
 }
 
 // host side: fast kernel on x in [1, n0-2], generic gather on the two x-ghost planes
-template <class T, bool FUSE>
-int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, const T *V, double dt_, const double *acc,
-                     bool has_acc) {
+template <class T, bool FUSE, bool COPY>
+int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u0out, const T *V, double dt_,
+                     const double *acc, bool has_acc) {
     const int ntx = (g.n[0] - 2 + CD_BX - 1) / CD_BX, nty = (g.n[1] + CD_BY - 1) / CD_BY;
     const int tpp = ((ntx * nty + 7) / 8) * 8;  // padded to a multiple of 8 for the XCD mapping (idle tail tiles)
     const int nown = g.zhi - g.zlo + 1;
@@ -230,8 +233,8 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, cons
     double a3[3] = {0, 0, 0};
     if (has_acc) for (int d = 0; d < 3; ++d) a3[d] = acc[d];
     Prof p(WL_K_CONVDIFF, g.cells());
-    hipLaunchKernelGGL((k_convdiff3<T, FUSE>), dim3(nblk), dim3(CD_BX * CD_BY), 0, ctx().stream, g, r, u, (T)nu_, u0, V,
-                       (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen);
+    hipLaunchKernelGGL((k_convdiff3<T, FUSE, COPY>), dim3(nblk), dim3(CD_BX * CD_BY), 0, ctx().stream, g, r, u, (T)nu_, u0,
+                       u0out, V, (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen);
     return (int)hipGetLastError();
 }
 

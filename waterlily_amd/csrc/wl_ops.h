@@ -130,9 +130,9 @@ int op_reduce(const G &g, int kclass, int op, double init, F cell, double *parti
 // each interior flux rounded to T first exactly like the Phi scratch does (:45-47); boundary faces are added
 // in Float64 like :54-55.  No Phi array, no 9x re-read of r, no write race.
 // FUSE: also applies accelerate! (:68-70) and the first BDIM! loop (:133): f = u0 + dt*r - V on ALL cells.
-template <class T, int D, bool FUSE>
+template <class T, int D, bool FUSE, bool COPY = false>
 int op_conv_diff_range(const G &g, const Range &R, T *r, const T *u, double nu_, int permask, const T *u0, const T *V,
-                       double dt_, const double *acc, bool has_acc) {
+                       double dt_, const double *acc, bool has_acc, T *u0out = nullptr) {
     const T nu = (T)nu_, dt = (T)dt_;
     double a3[3] = {0, 0, 0};
     if (has_acc) for (int d = 0; d < D; ++d) a3[d] = acc[d];
@@ -197,7 +197,9 @@ _Pragma("unroll")
             }
             if (FUSE) {
                 if (has_acc) rr = (T)((double)rr + (c == 0 ? a0 : (c == 1 ? a1 : a2)));
-                r[I + (long)c * gg.sc] = (u0[I + (long)c * gg.sc] + dt * rr) - V[I + (long)c * gg.sc];
+                const T uo = COPY ? ui[I] : u0[I + (long)c * gg.sc];
+                if (COPY) u0out[I + (long)c * gg.sc] = uo;
+                r[I + (long)c * gg.sc] = (uo + dt * rr) - V[I + (long)c * gg.sc];
             } else {
                 r[I + (long)c * gg.sc] = rr;
             }
@@ -207,20 +209,21 @@ _Pragma("unroll")
 
 // dispatch: D=3 non-periodic -> LDS-tiled marching kernel (wl_convdiff.h) + generic gather on the two x-ghost
 // planes; everything else (2-D, periodic directions) -> generic gather kernel over the whole array.
-template <class T, int D, bool FUSE>
+// COPY: also perform `u0 .= u` (Flow.jl:154) for the cells written (u0out), the epilogue then uses u itself.
+template <class T, int D, bool FUSE, bool COPY = false>
 int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T *u0, const T *V, double dt_,
-                 const double *acc, bool has_acc) {
+                 const double *acc, bool has_acc, T *u0out = nullptr) {
     if constexpr (D == 3) {
         if (ctx().opt[2] && permask == 0 && g.n[0] >= 5 && g.n[1] >= 5 && g.n[2] >= 5) {
-            WL_TRY((launch_convdiff3<T, FUSE>(g, r, u, nu_, u0, V, dt_, acc, has_acc)));
+            WL_TRY((launch_convdiff3<T, FUSE, COPY>(g, r, u, nu_, u0, u0out, V, dt_, acc, has_acc)));
             Range R0 = r_whole(g), R1 = r_whole(g);
             R0.hi[0] = 0;
             R1.lo[0] = g.n[0] - 1;
-            WL_TRY((op_conv_diff_range<T, D, FUSE>(g, R0, r, u, nu_, permask, u0, V, dt_, acc, has_acc)));
-            return op_conv_diff_range<T, D, FUSE>(g, R1, r, u, nu_, permask, u0, V, dt_, acc, has_acc);
+            WL_TRY((op_conv_diff_range<T, D, FUSE, COPY>(g, R0, r, u, nu_, permask, u0, V, dt_, acc, has_acc, u0out)));
+            return op_conv_diff_range<T, D, FUSE, COPY>(g, R1, r, u, nu_, permask, u0, V, dt_, acc, has_acc, u0out);
         }
     }
-    return op_conv_diff_range<T, D, FUSE>(g, r_whole(g), r, u, nu_, permask, u0, V, dt_, acc, has_acc);
+    return op_conv_diff_range<T, D, FUSE, COPY>(g, r_whole(g), r, u, nu_, permask, u0, V, dt_, acc, has_acc, u0out);
 }
 
 // accelerate!  src/Flow.jl:68-70: r[..,i] .+= g_i on every element
@@ -367,9 +370,62 @@ _Pragma("unroll")
     });
 }
 
+// 16-B vectorised form of the velocity correction for D=3 (same layout requirements as wl_stencil7.h)
+template <class T>
+__global__ __launch_bounds__(256) void k_correct3(G g, T *__restrict__ u, const T *__restrict__ L, const T *__restrict__ x,
+                                                  int ntx, int tpp, int nblk, int clen, int klo, int khi) {
+    constexpr int V = Vec16<T>::V;
+    using VA = VecA<T>;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);
+    const int ch = lb / tpp, pt = lb - ch * tpp;
+    const int i = 1 + (pt % ntx) * 64 * V + lane * V, j = 1 + (pt / ntx) * S7_BY + wv;
+    const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);
+    if (i > g.n[0] - 2 || j > g.n[1] - 2 || k0 >= k1) return;
+    const long sy = g.s[1], sz = g.s[2], sc = g.sc;
+    const long col = (long)i + sy * (long)j;
+    VA xm = VA::load(x + col + sz * (k0 - 1));
+    for (int k = k0; k < k1; ++k) {
+        const long o = col + sz * k;
+        const VA xc = VA::load(x + o), xy = VA::load(x + o - sy);
+        T left = __shfl_up(xc.v[V - 1], 1, 64);
+        if (lane == 0) left = x[o - 1];
+        VA u0 = VA::load(u + o), u1 = VA::load(u + o + sc), u2 = VA::load(u + o + 2 * sc);
+        const VA l0 = VA::load(L + o), l1 = VA::load(L + o + sc), l2 = VA::load(L + o + 2 * sc);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const T xl = (v == 0) ? left : xc.v[v == 0 ? 0 : v - 1];
+            u0.v[v] -= l0.v[v] * (xc.v[v] - xl);
+            u1.v[v] -= l1.v[v] * (xc.v[v] - xy.v[v]);
+            u2.v[v] -= l2.v[v] * (xc.v[v] - xm.v[v]);
+        }
+        u0.store(u + o); u1.store(u + o + sc); u2.store(u + o + 2 * sc);
+        xm = xc;
+    }
+}
+
 // u[I,i] -= L[I,i]*d_i x  src/Flow.jl:141-143 (three loops fused: they touch disjoint components)
 template <class T, int D>
 int op_correct(const G &g, T *u, const T *L, const T *x) {
+    if constexpr (D == 3) {
+        if (stencil7_ok<T>(g, u, L) && stencil7_ok<T>(g, x, L)) {
+            constexpr int V = Vec16<T>::V;
+            const Range R = r_inside(g);
+            if (R.count() <= 0) return 0;
+            const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + S7_BY - 1) / S7_BY;
+            const int tpp = ((ntx * nty + 7) / 8) * 8;
+            const int nown = R.hi[2] - R.lo[2] + 1;
+            int want = WL_MAXB / tpp;
+            if (want < 1) want = 1;
+            if (want > nown) want = nown;
+            const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
+            Prof p(WL_K_CORRECT, R.count());
+            hipLaunchKernelGGL((k_correct3<T>), dim3(tpp * nchunk), dim3(256), 0, ctx().stream, g, u, L, x, ntx, tpp,
+                               tpp * nchunk, clen, R.lo[2], R.hi[2]);
+            return (int)hipGetLastError();
+        }
+    }
     const G gg = g;
     return launch_range(WL_K_CORRECT, r_inside(g), [=] __device__(int i, int j, int k) {
         const long I = gg.at(i, j, k);
