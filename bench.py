@@ -59,8 +59,8 @@ def sphere(dims, T, Re=3700.0, device="cuda:0"):
     from waterlily_amd.body import AutoBody, norm2
     m = min(dims)
     radius = m / 8
-    c = torch.tensor([m / 2 - 1, dims[1] / 2 - 1, dims[2] / 2 - 1], dtype=torch.float64)[:, None]
-    body = AutoBody(lambda x, t: norm2(x - c) - radius)
+    cx, cy, cz = m / 2 - 1, dims[1] / 2 - 1, dims[2] / 2 - 1
+    body = AutoBody(lambda x, t: torch.sqrt((x[0] - cx) ** 2 + (x[1] - cy) ** 2 + (x[2] - cz) ** 2) - radius)
     return S.Simulation(tuple(dims), (1.0, 0.0, 0.0), 2 * radius, nu=2 * radius / Re, body=body, T=T, device=device)
 
 

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 __all__ = ["AutoBody", "NoBody", "measure", "sdf", "kern", "kern0", "kern1", "mu0", "mu1", "norm2",
-           "measure_fields", "nds_band"]
+           "measure_fields", "measure_fields_into", "nds_band"]
 
 
 def norm2(x: torch.Tensor) -> torch.Tensor:
@@ -75,7 +75,7 @@ def _as_points(x) -> Tuple[torch.Tensor, bool]:
 def sdf(body: AutoBody, x, t=0.0) -> torch.Tensor:
     """AutoBody.jl:38"""
     xp, single = _as_points(x)
-    d = body.sdf(xp, torch.as_tensor(float(t), dtype=torch.float64))
+    d = body.sdf(xp, torch.as_tensor(float(t), dtype=torch.float64, device=xp.device))
     d = torch.broadcast_to(d, (xp.shape[1],))
     return d[0] if single else d
 
@@ -83,14 +83,16 @@ def sdf(body: AutoBody, x, t=0.0) -> torch.Tensor:
 def measure(body: AutoBody, x, t=0.0, fastd2: float = math.inf):
     """AutoBody.jl:110-131: returns (d, n, V); n, V are zero where d^2 > fastd2.
 
-    d is corrected to a pseudo-sdf (d/|grad|), n is the unit normal, V = -J^-1 * dmap/dt."""
+    d is corrected to a pseudo-sdf (d/|grad|), n is the unit normal, V = -J^-1 * dmap/dt.
+    Runs on the device of `x` (CPU or GPU); torch autograd stands in for ForwardDiff."""
     xp, single = _as_points(x)
     D, M = xp.shape
-    tt = torch.as_tensor(float(t), dtype=torch.float64)
+    dev = xp.device
+    tt = torch.as_tensor(float(t), dtype=torch.float64, device=dev)
     xr = xp.detach().clone().requires_grad_(True)
     d = torch.broadcast_to(body.sdf(xr, tt), (M,))
-    n = torch.zeros(D, M, dtype=torch.float64)
-    V = torch.zeros(D, M, dtype=torch.float64)
+    n = torch.zeros(D, M, dtype=torch.float64, device=dev)
+    V = torch.zeros(D, M, dtype=torch.float64, device=dev)
     dv = d.detach().clone()
     near = dv * dv <= fastd2
     if bool(near.any()):
@@ -108,7 +110,7 @@ def measure(body: AutoBody, x, t=0.0, fastd2: float = math.inf):
             # J[a,b] = d map_a / d x_b ; dot = d map / d t  (forward-mode along t)
             xq = xp.detach().clone().requires_grad_(True)
             mo = body.map(xq, tt)
-            J = torch.zeros(M, D, D, dtype=torch.float64)
+            J = torch.zeros(M, D, D, dtype=torch.float64, device=dev)
             for a in range(D):
                 if mo.requires_grad:
                     (ga,) = torch.autograd.grad(mo[a].sum(), xq, retain_graph=True, allow_unused=True)
@@ -116,7 +118,7 @@ def measure(body: AutoBody, x, t=0.0, fastd2: float = math.inf):
                         J[:, a, :] = ga.T
             _, dot = torch.func.jvp(lambda s: body.map(xp, s), (tt,), (torch.ones_like(tt),))
             dot = torch.broadcast_to(dot, (D, M))
-            eye = torch.eye(D, dtype=torch.float64)[None]
+            eye = torch.eye(D, dtype=torch.float64, device=dev)[None]
             Js = torch.where(ok[:, None, None], J, eye)
             Vs = -torch.linalg.solve(Js, dot.T[..., None])[..., 0]
             V = torch.where(ok[None], Vs.T, V)
@@ -147,76 +149,110 @@ def mu1(d, eps):
     return eps * kern1(np.clip(np.asarray(d, dtype=np.float64) / eps, -1, 1))
 
 
+# torch twins of the moments (any device)
+def _kern_t(d):
+    return 0.5 + 0.5 * torch.cos(math.pi * d)
+
+
+def _mu0_t(d, eps):
+    d = torch.clamp(d / eps, -1, 1)
+    return 0.5 + 0.5 * d + 0.5 * torch.sin(math.pi * d) / math.pi
+
+
+def _mu1_t(d, eps):
+    d = torch.clamp(d / eps, -1, 1)
+    return eps * (0.25 * (1 - d * d) - 0.5 * (d * torch.sin(math.pi * d) + (1 + torch.cos(math.pi * d)) / math.pi) / math.pi)
+
+
 # --- field-level measure (Body.jl:31-50) --------------------------------------------------------------
 
-def _centres(Ng: Sequence[int], lo: int, hi: int) -> np.ndarray:
-    """loc(0,I) (util.jl:160) for all I with last index in [lo,hi): array (D, n0, .., hi-lo)."""
-    D = len(Ng)
-    ax = [np.arange(n, dtype=np.float64) - 0.5 for n in Ng[:-1]] + [np.arange(lo, hi, dtype=np.float64) - 0.5]
-    return np.stack(np.meshgrid(*ax, indexing="ij"))
+_TT = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
+
+
+def _chunk_points(Ng, lo, hi, device):
+    """cell centres loc(0,I) (util.jl:160) of the INTERIOR cells with global last index in [lo,hi):
+    returns (points (D, M) float64, shape of the chunk)"""
+    ax = [torch.arange(1, n - 1, dtype=torch.float64, device=device) - 0.5 for n in Ng[:-1]]
+    ax.append(torch.arange(lo, hi, dtype=torch.float64, device=device) - 0.5)
+    g = torch.meshgrid(*ax, indexing="ij")
+    shp = tuple(g[0].shape)
+    return torch.stack([q.reshape(-1) for q in g]), shp
+
+
+def measure_fields_into(body, dims: Sequence[int], mu0, mu1, V, dsdf, t: float = 0.0, eps: float = 1.0,
+                        chunk_cells: int = 1 << 22, slab=None) -> None:
+    """Body.jl:31-50 before the two BC! calls, written INTO the given torch tensors (any device, any strides):
+    mu0 (Nl...,D), mu1 (Nl...,D,D), V (Nl...,D), dsdf (Nl...) where Nl are the local extents (= Ng without a slab).
+    The user's sdf/map closures run on the tensors' device: on the GPU this is `measure!` without a host round trip."""
+    D = len(dims)
+    Ng = tuple(int(n) + 2 for n in dims)      # extents of the undecomposed array
+    dev, tdt = mu0.device, mu0.dtype
+    kz0 = slab.kz0 if slab is not None else 0
+    nl = mu0.shape[D - 1]
+    mu0.fill_(1)
+    mu1.zero_()
+    V.zero_()
+    if body is None or isinstance(body, NoBody):
+        return
+    d2 = float((2 + eps) ** 2)
+    plane = int(np.prod(Ng[:-1]))
+    step = max(1, chunk_cells // plane)
+    g_lo, g_hi = max(1, kz0), min(Ng[-1] - 1, kz0 + nl)   # global interior planes present locally
+    inner = tuple(slice(1, n - 1) for n in Ng[:-1])
+    for lo in range(g_lo, g_hi, step):
+        hi = min(g_hi, lo + step)
+        pts, shp = _chunk_points(Ng, lo, hi, dev)
+        dc = sdf(body, pts, t).to(tdt)                       # stored into sigma::T (Body.jl:34)
+        ksl = slice(lo - kz0, hi - kz0)
+        dsdf[inner + (ksl,)] = dc.reshape(shp)
+        band = (dc * dc) < torch.as_tensor(d2, dtype=tdt, device=dev)   # Body.jl:35, compared in T
+        inside_body = (~band) & (dc < 0)
+        if bool(inside_body.any()):
+            sub = mu0[inner + (ksl,)]
+            sub[inside_body.reshape(shp)] = 0                # all D components of those cells
+        if bool(band.any()):
+            bidx = torch.nonzero(band)[:, 0]
+            xb = pts[:, bidx]
+            sub = list(torch.unravel_index(bidx, shp))
+            full = tuple(s + 1 for s in sub[:-1]) + (sub[-1] + (lo - kz0),)
+            for i in range(D):
+                xf = xb.clone()
+                xf[i] -= 0.5                                  # face location loc(i,I) (util.jl:160)
+                di, ni, Vi = measure(body, xf, t, fastd2=d2)
+                V[full + (i,)] = Vi[i].to(tdt)
+                mu0[full + (i,)] = _mu0_t(di, eps).to(tdt)
+                k1 = _mu1_t(di, eps)
+                for j in range(D):
+                    mu1[full + (i, j)] = (k1 * ni[j]).to(tdt)
+
+
+def _fortran_empty(shape, tdt):
+    st, acc = [], 1
+    for n in shape:
+        st.append(acc)
+        acc *= n
+    return torch.empty_strided(tuple(shape), tuple(st), dtype=tdt)
 
 
 def measure_fields(body, dims: Sequence[int], t: float = 0.0, eps: float = 1.0, T=np.float32,
                    chunk_cells: int = 1 << 22, slab=None):
-    """Body.jl:31-50 before the two BC! calls: returns host arrays (mu0, mu1, V, d), Fortran order,
-    shaped (Ng...,D), (Ng...,D,D), (Ng...,D), (Ng...).  `d` holds sdf at the cell centres (the
-    reference stores it in flow.sigma).  Cells outside `inside(p)` keep mu0=1, mu1=V=0."""
+    """Host form of measure_fields_into: returns Fortran-ordered numpy arrays (mu0, mu1, V, d)."""
     D = len(dims)
-    Ng = tuple(int(n) + 2 for n in dims)      # extents of the undecomposed array
-    T = np.dtype(T)
-    # z-slab (waterlily_amd.dist.Slab): local arrays hold the global planes kz0 .. kz0+n2l-1, halos included --
-    # they are evaluated directly from the sdf, so no exchange is needed for the coefficient fields
-    kz0 = slab.kz0 if slab is not None else 0
+    Ng = tuple(int(n) + 2 for n in dims)
     Nl = Ng if slab is None else Ng[:-1] + (slab.n2l,)
-    m0 = np.ones(Nl + (D,), dtype=T, order="F")
-    m1 = np.zeros(Nl + (D, D), dtype=T, order="F")
-    Vv = np.zeros(Nl + (D,), dtype=T, order="F")
-    dd = np.zeros(Nl, dtype=T, order="F")
-    if body is None or isinstance(body, NoBody):
-        return m0, m1, Vv, dd
-    d2 = T.type((2 + eps) ** 2)
-    plane = int(np.prod(Ng[:-1]))
-    step = max(1, chunk_cells // plane)
-    g_lo, g_hi = max(1, kz0), min(Ng[-1] - 1, kz0 + Nl[-1])   # global interior planes present locally
-    for lo in range(g_lo, g_hi, step):
-        hi = min(g_hi, lo + step)
-        xc = _centres(Ng, lo, hi)
-        inner = tuple(slice(1, n - 1) for n in Ng[:-1]) + (slice(None),)
-        xc = xc[(slice(None),) + inner]                     # interior cells of this chunk
-        shp = xc.shape[1:]
-        pts = torch.from_numpy(np.ascontiguousarray(xc.reshape(D, -1)))
-        dc = sdf(body, pts, t).numpy().astype(T)             # stored into sigma::T (Body.jl:34)
-        sel = inner[:-1] + (slice(lo - kz0, hi - kz0),)
-        dd[sel] = dc.reshape(shp)
-        band = (dc * dc) < d2                                 # Body.jl:35, compared in T
-        inside_body = (~band) & (dc < 0)
-        if inside_body.any():
-            for i in range(D):
-                v = m0[sel + (i,)]
-                v[inside_body.reshape(shp)] = 0
-                m0[sel + (i,)] = v
-        if band.any():
-            bidx = np.nonzero(band)[0]
-            xb = np.ascontiguousarray(xc.reshape(D, -1)[:, bidx])
-            sub = np.unravel_index(bidx, shp)
-            full = tuple(s + 1 for s in sub[:-1]) + (sub[-1] + lo - kz0,)
-            for i in range(D):
-                xf = xb.copy()
-                xf[i] -= 0.5                                  # face location loc(i,I) (util.jl:160)
-                di, ni, Vi = measure(body, torch.from_numpy(xf), t, fastd2=float(d2))
-                di, ni, Vi = di.numpy(), ni.numpy(), Vi.numpy()
-                Vv[full + (i,)] = Vi[i].astype(T)
-                m0[full + (i,)] = mu0(di, eps).astype(T)
-                k1 = mu1(di, eps)
-                for j in range(D):
-                    m1[full + (i, j)] = (k1 * ni[j]).astype(T)
-    return m0, m1, Vv, dd
+    tdt = _TT[np.dtype(T)]
+    m0, m1 = _fortran_empty(Nl + (D,), tdt), _fortran_empty(Nl + (D, D), tdt)
+    Vv, dd = _fortran_empty(Nl + (D,), tdt), _fortran_empty(Nl, tdt)
+    dd.zero_()
+    measure_fields_into(body, dims, m0, m1, Vv, dd, t=t, eps=eps, chunk_cells=chunk_cells, slab=slab)
+    return m0.numpy(), m1.numpy(), Vv.numpy(), dd.numpy()
 
 
-def nds_band(body, dims: Sequence[int], t: float = 0.0, chunk_cells: int = 1 << 22, slab=None):
+def nds_band(body, dims: Sequence[int], t: float = 0.0, chunk_cells: int = 1 << 22, slab=None, device="cpu"):
     """Metrics.jl:84-87 evaluated over inside(p): returns (idx, nds) where idx are the column-major
-    linear indices (ghost-inclusive extents) of cells with a non-zero n*kern(clamp(d,-1,1)) and nds is
-    the (nband, D) Float64 array of those vectors (positions and normals in Float64, Metrics.jl:96)."""
+    linear indices (ghost-inclusive LOCAL extents) of cells with a non-zero n*kern(clamp(d,-1,1)) and nds is
+    the (nband, D) Float64 array of those vectors (positions and normals in Float64, Metrics.jl:96).
+    Returned as numpy arrays; `device` only selects where the closures are evaluated."""
     D = len(dims)
     Ng = tuple(int(n) + 2 for n in dims)
     strides = np.cumprod((1,) + Ng[:-1])
@@ -231,24 +267,19 @@ def nds_band(body, dims: Sequence[int], t: float = 0.0, chunk_cells: int = 1 << 
     g_hi = Ng[-1] - 1 if slab is None else min(Ng[-1] - 1, slab.kz0 + slab.own_hi + 1)
     for lo in range(g_lo, g_hi, step):
         hi = min(g_hi, lo + step)
-        xc = _centres(Ng, lo, hi)
-        inner = tuple(slice(1, n - 1) for n in Ng[:-1]) + (slice(None),)
-        xc = xc[(slice(None),) + inner]
-        shp = xc.shape[1:]
-        pts = np.ascontiguousarray(xc.reshape(D, -1))
-        dc = sdf(body, torch.from_numpy(pts), t).numpy()
-        near = np.nonzero(dc * dc <= 1.0 + 1e-9)[0]           # generous pre-filter; exact test below
-        if near.size == 0:
+        pts, shp = _chunk_points(Ng, lo, hi, device)
+        dc = sdf(body, pts, t)
+        near = torch.nonzero(dc * dc <= 1.0 + 1e-9)[:, 0]      # generous pre-filter; exact test in measure
+        if near.numel() == 0:
             continue
-        d, n, _ = measure(body, torch.from_numpy(np.ascontiguousarray(pts[:, near])), t, fastd2=1.0)
-        d, n = d.numpy(), n.numpy()
-        v = (n * kern(np.clip(d, -1, 1))[None]).T           # (m, D)
-        keep = np.any(v != 0, axis=1)
-        sub = np.unravel_index(near[keep], shp)
-        full = [s + 1 for s in sub[:-1]] + [sub[-1] + lo - kz0]
-        lin = sum(f.astype(np.int64) * int(s) for f, s in zip(full, strides))
-        idxs.append(lin)
-        vals.append(v[keep])
+        d, n, _ = measure(body, pts[:, near], t, fastd2=1.0)
+        v = (n * _kern_t(torch.clamp(d, -1, 1))[None]).T        # (m, D)
+        keep = (v != 0).any(1)
+        sub = torch.unravel_index(near[keep], shp)
+        full = [s + 1 for s in sub[:-1]] + [sub[-1] + (lo - kz0)]
+        lin = sum(f.to(torch.int64) * int(s) for f, s in zip(full, strides))
+        idxs.append(lin.cpu().numpy())
+        vals.append(v[keep].cpu().numpy())
     if not idxs:
         return np.zeros(0, dtype=np.int64), np.zeros((0, D))
     idx = np.concatenate(idxs)

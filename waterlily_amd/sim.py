@@ -568,7 +568,10 @@ class Simulation:
 
     def __init__(self, dims, u_BC, L, *, dt=0.25, nu=0.0, g=None, U=None, eps=1, perdir=(), ulam=None,
                  exitBC=False, body=None, T=np.float32, device="cuda:0", padded=True, slab="auto",
-                 replicate_cells=1 << 21):
+                 replicate_cells=1 << 21, geometry="device"):
+        """geometry: where the body's sdf/map closures are evaluated by measure! -- "device": on the GPU, written
+        straight into mu0/mu1/V (no host round trip; closures must be device-agnostic torch code); "host": on the
+        CPU then uploaded (bit-identical to what the CPU oracle is fed in the parity tests)."""
         assert not (callable(u_BC) and callable(ulam)), "`u_BC` and `uλ` cannot be both specified as Function"
         assert not (U is None and callable(u_BC)), "`U` must be specified if `u_BC` is a Function"
         if ulam is None:
@@ -576,6 +579,7 @@ class Simulation:
         self.U = float(np.sqrt(sum(float(v) ** 2 for v in u_BC))) if U is None else U
         self.L, self.eps = L, eps
         self.body = body if body is not None else B.NoBody()
+        self.geometry = geometry
         if slab == "auto":   # one z-slab per rank once a communicator exists (waterlily_amd.dist.init_*)
             from . import dist as _dist
             r, n = _dist.rank_size()
@@ -584,22 +588,27 @@ class Simulation:
         self.flow = Flow(dims, u_BC, ulam=ulam, dt=dt, nu=nu, g=g, T=T, perdir=perdir, exitBC=exitBC,
                          device=device, padded=padded, slab=slab)
         self._band = None
-        measure_flow(self.flow, self.body, t=0.0, eps=eps)
+        measure_flow(self.flow, self.body, t=0.0, eps=eps, geometry=geometry)
         self.pois = MultiLevelPoisson(self.flow.p, self.flow.mu0, self.flow.sigma, perdir=perdir, padded=padded,
                                       replicate_cells=replicate_cells)
 
 
-def measure_flow(a: Flow, body, t=0.0, eps=1) -> None:
-    """Body.jl:31-53: the user's sdf/map closures run on the host (body.measure_fields); the coefficient
-    fields are uploaded and the two BC! calls run on the device."""
+def measure_flow(a: Flow, body, t=0.0, eps=1, geometry="device") -> None:
+    """Body.jl:31-53: the user's sdf/map closures are evaluated with torch (autograd = ForwardDiff) either on the
+    GPU, straight into the coefficient fields, or on the host followed by an upload; the two BC! calls, the halo
+    exchange and the row flags run in the library."""
     if isinstance(body, B.NoBody):
         flow_update(a)
         return
-    mu0, mu1, V, d = B.measure_fields(body, tuple(n - 2 for n in a.N), t=t, eps=eps, T=a.T, slab=a.slab)
-    upload(a.mu0, mu0)
-    upload(a.mu1, mu1)
-    upload(a.V, V)
-    a.sigma[inside(a.sigma)] = torch.from_numpy(np.ascontiguousarray(d[inside(d)])).to(a.sigma.device)
+    dims = tuple(n - 2 for n in a.N)
+    if geometry == "device":
+        B.measure_fields_into(body, dims, a.mu0, a.mu1, a.V, a.sigma, t=t, eps=eps, slab=a.slab)
+    else:
+        mu0, mu1, V, d = B.measure_fields(body, dims, t=t, eps=eps, T=a.T, slab=a.slab)
+        upload(a.mu0, mu0)
+        upload(a.mu1, mu1)
+        upload(a.V, V)
+        a.sigma[inside(a.sigma)] = torch.from_numpy(np.ascontiguousarray(d[inside(d)])).to(a.sigma.device)
     BC(a.mu0, (0.0,) * a.D, False, a.perdir)
     BC(a.V, (0.0,) * a.D, a.exitBC, a.perdir)
     halo_exchange(a.mu0, 2)   # (mu1 needs no exchange: the host evaluated the halo planes from the sdf directly)
@@ -620,7 +629,7 @@ def sim_time(sim: Simulation) -> float:
 def measure(sim: Simulation, t=None) -> None:
     """WaterLily.jl:116-119"""
     t = float(np.sum(np.asarray(sim.flow.dt, dtype=np.float64))) if t is None else t
-    measure_flow(sim.flow, sim.body, t=t, eps=sim.eps)
+    measure_flow(sim.flow, sim.body, t=t, eps=sim.eps, geometry=sim.geometry)
     sim._band = None
     update(sim.pois)
 
@@ -662,6 +671,7 @@ def band_to_device(p: torch.Tensor, idx: np.ndarray, nds: np.ndarray):
 def pressure_force(sim: Simulation) -> np.ndarray:
     """Metrics.jl:94-95"""
     if sim._band is None or sim._band[0] != time(sim.flow):
-        idx, nds = B.nds_band(sim.body, tuple(n - 2 for n in sim.flow.N), t=time(sim.flow), slab=sim.slab)
+        idx, nds = B.nds_band(sim.body, tuple(n - 2 for n in sim.flow.N), t=time(sim.flow), slab=sim.slab,
+                              device=sim.flow.device if sim.geometry == "device" else "cpu")
         sim._band = (time(sim.flow),) + band_to_device(sim.flow.p, idx, nds)
     return pressure_force_band(sim.flow.p, sim._band[1], sim._band[2])
