@@ -240,10 +240,10 @@ __device__ inline double wave_red(double v, int op) {
     }
     return v;
 }
-// block reduction of NV values per thread; result valid in thread 0
-template <int NV>
+// block reduction of NV values per thread over NW wavefronts; result valid in thread 0
+template <int NV, int NW = WL_BY>
 __device__ inline void block_red(double (&v)[NV], int op) {
-    __shared__ double sm[NV][WL_BY];
+    __shared__ double sm[NV][NW];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
@@ -255,7 +255,7 @@ __device__ inline void block_red(double (&v)[NV], int op) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             double x = sm[q][0];
-            for (int i = 1; i < WL_BY; ++i) x = (op == RED_SUM) ? x + sm[q][i] : (sm[q][i] > x ? sm[q][i] : x);
+            for (int i = 1; i < NW; ++i) x = (op == RED_SUM) ? x + sm[q][i] : (sm[q][i] > x ? sm[q][i] : x);
             v[q] = x;
         }
     }

@@ -372,7 +372,7 @@ _Pragma("unroll")
 
 // 16-B vectorised form of the velocity correction for D=3 (same layout requirements as wl_stencil7.h)
 template <class T>
-__global__ __launch_bounds__(256) void k_correct3(G g, T *__restrict__ u, const T *__restrict__ L, const T *__restrict__ x,
+__global__ __launch_bounds__(64 * S7_BY) void k_correct3(G g, T *__restrict__ u, const T *__restrict__ L, const T *__restrict__ x,
                                                   int ntx, int tpp, int nblk, int clen, int klo, int khi) {
     constexpr int V = Vec16<T>::V;
     using VA = VecA<T>;
@@ -421,7 +421,7 @@ int op_correct(const G &g, T *u, const T *L, const T *x) {
             if (want > nown) want = nown;
             const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
             Prof p(WL_K_CORRECT, R.count());
-            hipLaunchKernelGGL((k_correct3<T>), dim3(tpp * nchunk), dim3(256), 0, ctx().stream, g, u, L, x, ntx, tpp,
+            hipLaunchKernelGGL((k_correct3<T>), dim3(tpp * nchunk), dim3(64 * S7_BY), 0, ctx().stream, g, u, L, x, ntx, tpp,
                                tpp * nchunk, clen, R.lo[2], R.hi[2]);
             return (int)hipGetLastError();
         }

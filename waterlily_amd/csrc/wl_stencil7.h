@@ -39,7 +39,7 @@ template <class T> struct VecA {   // array view of a 16-B vector
     }
 };
 
-constexpr int S7_BY = 4;
+constexpr int S7_BY = 4;   // rows (= wavefronts) per workgroup of the helper kernels (k_correct3)
 
 // ---- stencil operand sources: vec(o,i,j,k) = the V cells starting at (i,j,k) [offset o], scal = one cell
 template <class T> struct SrcArray {          // e is an array (pcg!: eps, residual!: x, increment!: eps)
@@ -82,8 +82,8 @@ template <class T> struct SrcProlong {        // e[I] = coarse x[down(I)] inside
     }
 };
 
-template <class T, int NRED, class SRC, class EPI>
-__global__ __launch_bounds__(256) void k_stencil7(G g, SRC src, const T *__restrict__ L, EPI epi,
+template <class T, int NRED, int BY, class SRC, class EPI>
+__global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__restrict__ L, EPI epi,
                                                   double *partials, int ntx, int tpp, int nblk, int clen, int klo,
                                                   int khi) {
     constexpr int V = Vec16<T>::V;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_stencil7(G g, SRC src, const T *__restr
     const int ch = lb / tpp, pt = lb - ch * tpp;
     const int nxi = g.n[0] - 2, nyi = g.n[1] - 2;
     const int i = 1 + (pt % ntx) * 64 * V + lane * V;
-    const int j = 1 + (pt / ntx) * S7_BY + wv;
+    const int j = 1 + (pt / ntx) * BY + wv;
     const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);
     double acc[NRED > 0 ? NRED : 1];
 #pragma unroll
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_stencil7(G g, SRC src, const T *__restr
         }
     }
     if (NRED > 0) {
-        block_red<(NRED > 0 ? NRED : 1)>(acc, RED_SUM);
+        block_red<(NRED > 0 ? NRED : 1), BY>(acc, RED_SUM);
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int q = 0; q < NRED; ++q) partials[(long)q * gridDim.x + blockIdx.x] = acc[q];
@@ -155,15 +155,17 @@ template <class T> inline bool stencil7_ok(const G &g, const T *e, const T *L) {
            (g.sc * sizeof(T)) % 16 == 0;
 }
 
-// launch over the owned interior planes; *np = number of partials per reduced value (0 if nothing to do)
-template <class T, int NRED, class SRC, class EPI>
-inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, EPI epi, double *partials, int *np) {
+// launch over the owned interior planes; *np = number of partials per reduced value (0 if nothing to do).
+// BY = rows (wavefronts) per workgroup: 4 (256 threads) or 8 (512 threads; fewer y-halo rows re-read at tile edges),
+// selected by wl_set_option(4, .).
+template <class T, int NRED, int BY, class SRC, class EPI>
+inline int launch_stencil7_by(int kclass, const G &g, SRC src, const T *L, EPI epi, double *partials, int *np) {
     constexpr int V = Vec16<T>::V;
     Range R = r_inside(g);
     if (np) *np = 0;
     if (R.count() <= 0) return 0;
     const int klo = R.lo[2], khi = R.hi[2];
-    const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + S7_BY - 1) / S7_BY;
+    const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + BY - 1) / BY;
     const int tpp = ((ntx * nty + 7) / 8) * 8;
     const int nown = khi - klo + 1;
     int want = WL_MAXB / tpp;
@@ -175,9 +177,14 @@ inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, EPI epi,
     if (nblk > WL_MAXB) return -1;   // plane too large for the partial buffer: caller falls back
     if (np) *np = nblk;
     Prof p(kclass, R.count());
-    hipLaunchKernelGGL((k_stencil7<T, NRED, SRC, EPI>), dim3(nblk), dim3(256), 0, ctx().stream, g, src, L, epi, partials, ntx,
-                       tpp, nblk, clen, klo, khi);
+    hipLaunchKernelGGL((k_stencil7<T, NRED, BY, SRC, EPI>), dim3(nblk), dim3(64 * BY), 0, ctx().stream, g, src, L, epi, partials,
+                       ntx, tpp, nblk, clen, klo, khi);
     return (int)hipGetLastError();
+}
+template <class T, int NRED, class SRC, class EPI>
+inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, EPI epi, double *partials, int *np) {
+    if (ctx().opt[4]) return launch_stencil7_by<T, NRED, 8>(kclass, g, src, L, epi, partials, np);
+    return launch_stencil7_by<T, NRED, 4>(kclass, g, src, L, epi, partials, np);
 }
 
 }  // namespace wl
