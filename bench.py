@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default=None, help="force the kernel class reported in `roofline`")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "host"],
+                    help="multi-rank transport: rccl (one GPU per rank) or host (gloo staging; lets ranks share a GPU, tests)")
     ap.add_argument("--grid", type=int, nargs=3, default=None,
                     help="explicit GLOBAL grid nx ny nz (strong scaling, e.g. 1024 1024 512 = BASELINE configs[3])")
     args = ap.parse_args()
@@ -127,12 +129,17 @@ def main():
     L = _lib.lib()
     T = np.float32 if args.dtype == "f32" else np.float64
     tsz = np.dtype(T).itemsize
+    if args.comm == "host":
+        local = local % max(1, torch.cuda.device_count())
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 and args.comm == "rccl":
         # one process per GPU; the z axis is cut into `world` slabs, halos + scalar all-reduces run over RCCL (xGMI)
         dist.init_process_group("nccl", device_id=torch.device(dev))
         wd.init_rccl()
+    elif world > 1:
+        dist.init_process_group("gloo")
+        wd.init_host()
     m = args.size
     # N=1: the BASELINE 512^3 cube.  N>1 (default): WEAK scaling -- every GPU keeps a 512x512x512 slab, i.e. the
     # global grid is 512 x 512 x 512N; --grid gives an explicit global grid instead (strong scaling).
@@ -178,7 +185,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:  # MAX over ranks
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.comm == "rccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     nl, nc, ms = C.c_int64(), C.c_int64(), C.c_double()

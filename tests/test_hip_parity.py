@@ -432,3 +432,37 @@ def test_device_geometry_matches_host():
         S.sim_step(s)
     assert sims[0].pois.n == sims[1].pois.n and sims[0].pois.n[:2] == [2, 1]
     assert np.allclose(S.to_host(sims[0].flow.u), S.to_host(sims[1].flow.u), atol=1e-4)
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_noncubic_partial_tiles(T):
+    """Shapes that leave partially filled 64-wide (conv_diff) and 256-wide (vector stencil) tiles plus several tiles
+    per row, like the reference's README example (96,64,64): operators bit-exact, a whole solve and steps close."""
+    Ng = (96 + 2, 32 + 2, 16 + 2)
+    D = 3
+    u = rnd(Ng + (D,), T, 41)
+    r, Phi = O.zeros(Ng + (D,), T), O.zeros(Ng, T)
+    O.conv_diff(r, u, Phi, nu=0.02)
+    ud, rd = field(u, D), field(rnd(Ng + (D,), T, 42), D)
+    S.conv_diff(rd, ud, nu=0.02)
+    same(rd, r)
+    po, ph = make_pois(Ng, T, O.MultiLevelPoisson, S.MultiLevelPoisson, seed=50)
+    O.residual(po)
+    S.residual(ph)
+    S.upload(lev_h(ph).r, lev_o(po).r)
+    O.Jacobi(po)
+    S.Jacobi(ph)
+    same(lev_h(ph).r, lev_o(po).r)
+    same(ph.x, po.x)
+    O.Vcycle(po)
+    S.Vcycle(ph)
+    same(lev_h(ph).r, lev_o(po).r, exact=False, tol=rtol(T))
+    O.solver(po)
+    S.solver(ph)
+    assert po.n == ph.n
+    same(ph.x, po.x, exact=False, tol=10 * rtol(T))
+    m = 32
+    R = m / 8
+    body = AutoBody(lambda x, t: norm2(x - (m / 2 - 1)) - R)
+    so, sh = pair((96, m, m), (1.0, 0.0, 0.0), 2 * R, nu=2 * R / 250, body=body, T=T)
+    check_step(so, sh, T, 2)

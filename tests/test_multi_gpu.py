@@ -95,3 +95,18 @@ def test_rccl_bootstrap_world1():
     comes up and a decomposed run works on it; only world size 1 is possible on a 1-GPU box."""
     out = run_workers("mg_worker.py", 1, "sphere_rccl_f32")
     check(out, "f32")
+
+
+@pytest.mark.gpu
+def test_bench_multirank_path():
+    """bench.py's N>1 code path (slab set-up, timing reduction, JSON line) with 2 ranks sharing the GPU over gloo."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "host", "--size", "64",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert "64x64x128" in out["config"]["workload"]
