@@ -378,14 +378,31 @@ __device__ inline float median3(float a, float b, float c) { return __builtin_am
 __device__ inline double median3(double a, double b, double c) {
     return fmax(fmin(a, b), fmin(fmax(a, b), c));
 }
+// x/6 correctly rounded WITHOUT the ~10-instruction IEEE division sequence (Markstein): q0 = rn(x*z), z = rn(1/6);
+// r = x - 6*q0 exactly (fma); q = rn(q0 + r*z).  The correction term is off by < 2^-24 ulp(q), and x/6 can never be
+// closer than ulp(q)/6 to a rounding midpoint (x is an even, 6*midpoint an odd multiple of ulp(q)), so q == rn(x/6)
+// for every x whose quotient is a normal number: bit-identical to the oracle's true division.
+__device__ __forceinline__ float div6(float x) {
+    const float z = 1.0f / 6.0f;
+    const float q0 = x * z;
+    const float r = __fmaf_rn(-6.0f, q0, x);
+    return __fmaf_rn(r, z, q0);
+}
+__device__ __forceinline__ double div6(double x) {
+    const double z = 1.0 / 6.0;
+    const double q0 = x * z;
+    const double r = __fma_rn(-6.0, q0, x);
+    return __fma_rn(r, z, q0);
+}
 // src/Flow.jl:4
 template <class T> __device__ inline T quick(T u, T c, T d) {
-    T a1 = (((T)5 * c + (T)2 * d) - u) / (T)6;
+    T a1 = div6(((T)5 * c + (T)2 * d) - u);
     T a2 = median3((T)10 * c - (T)9 * u, c, d);
     return median3(a1, c, a2);
 }
 // src/Flow.jl:3 : T add, then *0.5 in Float64
-template <class T> __device__ inline double phi(const T *f, long I, long s) { return (double)(T)(f[I] + f[I - s]) * 0.5; }
+// (the *0.5 is done in T before widening: scaling by a power of two is exact, so the Float64 value is the same)
+template <class T> __device__ inline double phi(const T *f, long I, long s) { return (double)((T)(f[I] + f[I - s]) * (T)0.5); }
 // src/Flow.jl:6
 // (the upwind triple is selected first, then ONE quick is evaluated: same value, half the arithmetic)
 template <class T> __device__ inline double phiu(const T *f, long I, long s, double u) {

@@ -34,7 +34,7 @@ __device__ __forceinline__ double cd_flux(T fm2, T fm1, T f0, T fp1, double uf, 
     const bool neg = uf < 0;
     const bool up = topbnd ? !neg : (uf > 0);      // phiuR takes the upwind-from-below triple unless u<0
     const T q = quick<T>(up ? fm2 : fp1, up ? fm1 : f0, up ? f0 : fm1);
-    const double cen = (double)(T)(f0 + fm1) * 0.5;
+    const double cen = (double)((T)(f0 + fm1) * (T)0.5);
     const bool central = (lowbnd && uf > 0) || (topbnd && neg);
     const double flux = uf * (central ? cen : (double)q);
     const T nud = nu * (T)(f0 - fm1);
@@ -141,18 +141,18 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
             const T *P = SM(s1, c) + own_l;  // plane k, component c, centred on the own cell
             // ---- z: lower face of cell k (also the upper face of the carried cell k-1)
             double ufz;
-            if (c == 0) ufz = (double)(T)(W[2][2] + SM(s1, 2)[own_l - 1]) * 0.5;
-            else if (c == 1) ufz = (double)(T)(W[2][2] + SM(s1, 2)[own_l - CD_W]) * 0.5;
-            else ufz = (double)(T)(W[2][2] + W[2][1]) * 0.5;
+            if (c == 0) ufz = (double)((T)(W[2][2] + SM(s1, 2)[own_l - 1]) * (T)0.5);
+            else if (c == 1) ufz = (double)((T)(W[2][2] + SM(s1, 2)[own_l - CD_W]) * (T)0.5);
+            else ufz = (double)((T)(W[2][2] + W[2][1]) * (T)0.5);
             Fz[c] = cd_flux<T>(W[c][0], W[c][1], W[c][2], W[c][3], ufz, nu, zlb, ztb);
             if (own && lowok) {
                 // ---- x: lower face i, upper face i+1
                 const T xm2 = P[-2], xm1 = P[-1], x0 = W[c][2], xp1 = P[1], xp2 = P[2];
                 double ufl, ufu;
                 const T *PX = SM(s1, 0) + own_l;
-                if (c == 0) { ufl = (double)(T)(PX[0] + PX[-1]) * 0.5; ufu = (double)(T)(PX[1] + PX[0]) * 0.5; }
-                else if (c == 1) { ufl = (double)(T)(PX[0] + PX[-CD_W]) * 0.5; ufu = (double)(T)(PX[1] + PX[1 - CD_W]) * 0.5; }
-                else { ufl = (double)(T)(PX[0] + W[0][1]) * 0.5; ufu = (double)(T)(PX[1] + SM(s0, 0)[own_l + 1]) * 0.5; }
+                if (c == 0) { ufl = (double)((T)(PX[0] + PX[-1]) * (T)0.5); ufu = (double)((T)(PX[1] + PX[0]) * (T)0.5); }
+                else if (c == 1) { ufl = (double)((T)(PX[0] + PX[-CD_W]) * (T)0.5); ufu = (double)((T)(PX[1] + PX[1 - CD_W]) * (T)0.5); }
+                else { ufl = (double)((T)(PX[0] + W[0][1]) * (T)0.5); ufu = (double)((T)(PX[1] + SM(s0, 0)[own_l + 1]) * (T)0.5); }
                 const bool xlb = (i == 1), xtb = (i == n0 - 2);
                 rr[c] = cd_add<T>(rr[c], cd_flux<T>(xm2, xm1, x0, xp1, ufl, nu, xlb, false), xlb);
                 rr[c] = cd_sub<T>(rr[c], cd_flux<T>(xm1, x0, xp1, xp2, ufu, nu, false, xtb), xtb);
@@ -161,9 +161,9 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
                     const T ym2 = P[-2 * CD_W], ym1 = P[-CD_W], yp1 = P[CD_W], yp2 = P[2 * CD_W];
                     const T *PY = SM(s1, 1) + own_l;
                     double vfl, vfu;
-                    if (c == 0) { vfl = (double)(T)(PY[0] + PY[-1]) * 0.5; vfu = (double)(T)(PY[CD_W] + PY[CD_W - 1]) * 0.5; }
-                    else if (c == 1) { vfl = (double)(T)(PY[0] + PY[-CD_W]) * 0.5; vfu = (double)(T)(PY[CD_W] + PY[0]) * 0.5; }
-                    else { vfl = (double)(T)(PY[0] + W[1][1]) * 0.5; vfu = (double)(T)(PY[CD_W] + SM(s0, 1)[own_l + CD_W]) * 0.5; }
+                    if (c == 0) { vfl = (double)((T)(PY[0] + PY[-1]) * (T)0.5); vfu = (double)((T)(PY[CD_W] + PY[CD_W - 1]) * (T)0.5); }
+                    else if (c == 1) { vfl = (double)((T)(PY[0] + PY[-CD_W]) * (T)0.5); vfu = (double)((T)(PY[CD_W] + PY[0]) * (T)0.5); }
+                    else { vfl = (double)((T)(PY[0] + W[1][1]) * (T)0.5); vfu = (double)((T)(PY[CD_W] + SM(s0, 1)[own_l + CD_W]) * (T)0.5); }
                     const bool ylb = (j == 1), ytb = (j == n1 - 2);
                     rr[c] = cd_add<T>(rr[c], cd_flux<T>(ym2, ym1, x0, yp1, vfl, nu, ylb, false), ylb);
                     rr[c] = cd_sub<T>(rr[c], cd_flux<T>(ym1, x0, yp1, yp2, vfu, nu, false, ytb), ytb);
