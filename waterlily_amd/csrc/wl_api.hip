@@ -32,6 +32,8 @@ struct RcclComm : Comm {
     int allgather(void *buf, size_t bytes) override {
         return chk(ncclAllGather((const char *)buf + (size_t)rank * bytes, buf, bytes, ncclChar, nc, ctx().stream), "allgather");
     }
+    int group_begin() override { return chk(ncclGroupStart(), "groupStart"); }   // NCCL groups nest
+    int group_end() override { return chk(ncclGroupEnd(), "groupEnd"); }
 };
 
 // Host-callback twin (tests: 2+ ranks sharing one GPU, transport = torch.distributed gloo).  Every operation

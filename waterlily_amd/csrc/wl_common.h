@@ -33,10 +33,12 @@ struct Comm {
     virtual int allreduce(double *dev, int n, int op) = 0;                       // op: 0 sum, 1 max; in place
     virtual int sendrecv(const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi, size_t bytes) = 0;
     virtual int allgather(void *buf, size_t bytes_per_rank) = 0;                  // in place, rank r at r*bytes
+    virtual int group_begin() { return 0; }   // several sendrecv calls issued as ONE batch (one latency, not one each)
+    virtual int group_end() { return 0; }
 };
 
 struct Ctx {
-    int opt[8] = {1, 1, 1, 1, 0, 0, 0, 0};   // wl_set_option
+    int opt[8] = {1, 1, 1, 1, 0, 1, 0, 0};   // wl_set_option
     Comm *comm = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -356,14 +358,16 @@ template <class T> inline int halo_exchange(const G &g, T *a, int ncomp, int dep
     if (!g.dist || !cm || cm->size == 1) return 0;
     const size_t bytes = (size_t)depth * (size_t)g.s[2] * sizeof(T);
     const bool lo = cm->rank > 0, hi = cm->rank < cm->size - 1;
+    int rc = cm->group_begin();
+    if (rc) return rc;
     for (int c = 0; c < ncomp; ++c) {
         T *b = a + (long)c * g.sc;
-        int rc = cm->sendrecv(lo ? b + (long)g.zlo * g.s[2] : nullptr, lo ? b + (long)(g.zlo - depth) * g.s[2] : nullptr,
-                              hi ? b + (long)(g.zhi - depth + 1) * g.s[2] : nullptr,
-                              hi ? b + (long)(g.zhi + 1) * g.s[2] : nullptr, bytes);
-        if (rc) return rc;
+        rc = cm->sendrecv(lo ? b + (long)g.zlo * g.s[2] : nullptr, lo ? b + (long)(g.zlo - depth) * g.s[2] : nullptr,
+                          hi ? b + (long)(g.zhi - depth + 1) * g.s[2] : nullptr,
+                          hi ? b + (long)(g.zhi + 1) * g.s[2] : nullptr, bytes);
+        if (rc) { (void)cm->group_end(); return rc; }
     }
-    return 0;
+    return cm->group_end();
 }
 
 // ------------------------------------------------------------------------------------------ device math

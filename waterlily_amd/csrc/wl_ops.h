@@ -674,7 +674,25 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st)
     const Range R = r_inside(p.g);
     const T eps10 = (T)10 * Lim<T>::eps;
     int np = 0;
+    // streaming pcg kernels in 16-B vector form where the layout allows (wl_set_option(5,0) = scalar range kernels)
+    bool vec = false;
+    if constexpr (D == 3)
+        vec = ctx().opt[5] && stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.z, p.r) && stencil7_ok<T>(p.g, p.x, p.iD);
+    using VA = VecA<T>;
     // :125-127
+    int rv0 = -1;
+    if (vec) {
+        rv0 = launch_rowvec<T, 1>(WL_K_PCG_INIT, p.g, [=] __device__(long o, double *acc) {
+            const VA rr = VA::load(q.r + o), id = VA::load(q.iD + o);
+            VA zv;
+_Pragma("unroll")
+            for (int v = 0; v < VA::V; ++v) { zv.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zv.v[v]; }
+            zv.store(q.z + o);
+            zv.store(q.eps + o);
+        }, partials, &np);
+        if (rv0 > 0) return rv0;
+    }
+    if (rv0 != 0)
     WL_TRY((launch_range_red<1>(WL_K_PCG_INIT, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
         const long I = q.g.at(i, j, k);
         const T v = q.r[I] * q.iD[I];
@@ -720,6 +738,28 @@ _Pragma("unroll")
         })));
         const bool last = (n == it);
         // :133-137
+        int rvu = -1;
+        if (vec) {
+            rvu = launch_rowvec<T, 1>(WL_K_PCG_UPDATE, p.g, [=] __device__(long o, double *acc) {
+                if (!st->active) return;
+                const T alpha = (T)st->alpha;
+                VA xv = VA::load(q.x + o), rr = VA::load(q.r + o);
+                const VA ev = VA::load(q.eps + o), zv = VA::load(q.z + o);
+_Pragma("unroll")
+                for (int v = 0; v < VA::V; ++v) { xv.v[v] += alpha * ev.v[v]; rr.v[v] = rr.v[v] - alpha * zv.v[v]; }
+                xv.store(q.x + o);
+                rr.store(q.r + o);
+                if (!last) {
+                    const VA id = VA::load(q.iD + o);
+                    VA zn;
+_Pragma("unroll")
+                    for (int v = 0; v < VA::V; ++v) { zn.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zn.v[v]; }
+                    zn.store(q.z + o);
+                }
+            }, partials, &np);
+            if (rvu > 0) return rvu;
+        }
+        if (rvu != 0)
         WL_TRY((launch_range_red<1>(WL_K_PCG_UPDATE, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
             if (!st->active) return;
             const long I = q.g.at(i, j, k);
@@ -744,6 +784,20 @@ _Pragma("unroll")
         })));
         if (last) break;
         // :140
+        int rvd = -1;
+        if (vec) {
+            rvd = launch_rowvec<T, 0>(WL_K_PCG_DIR, p.g, [=] __device__(long o, double *) {
+                if (!st->active) return;
+                const T beta = (T)st->beta;
+                VA ev = VA::load(q.eps + o);
+                const VA zv = VA::load(q.z + o);
+_Pragma("unroll")
+                for (int v = 0; v < VA::V; ++v) ev.v[v] = beta * ev.v[v] + zv.v[v];
+                ev.store(q.eps + o);
+            }, nullptr, nullptr);
+            if (rvd > 0) return rvd;
+        }
+        if (rvd != 0)
         WL_TRY(launch_range(WL_K_PCG_DIR, R, [=] __device__(int i, int j, int k) {
             if (!st->active) return;
             const long I = q.g.at(i, j, k);

@@ -145,6 +145,55 @@ __global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__r
     }
 }
 
+// ---- 16-B vectorised streaming (no neighbours): f(o, acc) is called once per V-cell vector at element offset o.
+// Same row mapping as k_stencil7 (lane = V cells of a row, wavefront = row segment, workgroup = 4 rows marching in z).
+template <class T, int NRED, class F>
+__global__ __launch_bounds__(256) void k_rowvec(G g, F f, double *partials, int ntx, int tpp, int nblk, int clen, int klo,
+                                                int khi) {
+    constexpr int V = Vec16<T>::V;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);
+    const int ch = lb / tpp, pt = lb - ch * tpp;
+    const int i = 1 + (pt % ntx) * 64 * V + lane * V, j = 1 + (pt / ntx) * 4 + wv;
+    const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);
+    double acc[NRED > 0 ? NRED : 1];
+#pragma unroll
+    for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) acc[q] = 0.0;
+    if (i <= g.n[0] - 2 && j <= g.n[1] - 2) {
+        const long col = (long)i + g.s[1] * (long)j;
+        for (int k = k0; k < k1; ++k) f(col + g.s[2] * k, acc);
+    }
+    if (NRED > 0) {
+        block_red<(NRED > 0 ? NRED : 1), 4>(acc, RED_SUM);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 0; q < NRED; ++q) partials[(long)q * gridDim.x + blockIdx.x] = acc[q];
+        }
+    }
+}
+template <class T, int NRED, class F>
+inline int launch_rowvec(int kclass, const G &g, F f, double *partials, int *np) {
+    constexpr int V = Vec16<T>::V;
+    Range R = r_inside(g);
+    if (np) *np = 0;
+    if (R.count() <= 0) return 0;
+    const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + 3) / 4;
+    const int tpp = ((ntx * nty + 7) / 8) * 8;
+    const int nown = R.hi[2] - R.lo[2] + 1;
+    int want = WL_MAXB / tpp;
+    if (want < 1) want = 1;
+    if (want > nown) want = nown;
+    const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
+    const int nblk = tpp * nchunk;
+    if (nblk > WL_MAXB) return -1;
+    if (np) *np = nblk;
+    Prof p(kclass, R.count());
+    hipLaunchKernelGGL((k_rowvec<T, NRED, F>), dim3(nblk), dim3(256), 0, ctx().stream, g, f, partials, ntx, tpp, nblk, clen,
+                       R.lo[2], R.hi[2]);
+    return (int)hipGetLastError();
+}
+
 // can the vector kernel run on this level?
 template <class T> inline bool stencil7_ok(const G &g, const T *e, const T *L) {
     constexpr int V = Vec16<T>::V;
