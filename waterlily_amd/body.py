@@ -180,20 +180,28 @@ def _chunk_points(Ng, lo, hi, device):
 
 
 def measure_fields_into(body, dims: Sequence[int], mu0, mu1, V, dsdf, t: float = 0.0, eps: float = 1.0,
-                        chunk_cells: int = 1 << 22, slab=None) -> None:
+                        chunk_cells: Optional[int] = None, slab=None):
     """Body.jl:31-50 before the two BC! calls, written INTO the given torch tensors (any device, any strides):
     mu0 (Nl...,D), mu1 (Nl...,D,D), V (Nl...,D), dsdf (Nl...) where Nl are the local extents (= Ng without a slab).
-    The user's sdf/map closures run on the tensors' device: on the GPU this is `measure!` without a host round trip."""
+    The user's sdf/map closures run on the tensors' device: on the GPU this is `measure!` without a host round trip.
+    Returns the LOCAL column-major linear indices (int64 tensor) of the band cells d^2 < (2+eps)^2, which
+    `nds_band(candidates=...)` can reuse so that pressure_force does not have to scan the grid again."""
     D = len(dims)
     Ng = tuple(int(n) + 2 for n in dims)      # extents of the undecomposed array
     dev, tdt = mu0.device, mu0.dtype
+    if chunk_cells is None:                    # big chunks on the GPU: few launches, few host syncs
+        chunk_cells = (1 << 25) if dev.type == "cuda" else (1 << 22)
+    lstrides = [1]
+    for n in mu0.shape[:D - 1]:
+        lstrides.append(lstrides[-1] * int(n))
+    cand = []
     kz0 = slab.kz0 if slab is not None else 0
     nl = mu0.shape[D - 1]
     mu0.fill_(1)
     mu1.zero_()
     V.zero_()
     if body is None or isinstance(body, NoBody):
-        return
+        return torch.zeros(0, dtype=torch.int64, device=dev)
     d2 = float((2 + eps) ** 2)
     plane = int(np.prod(Ng[:-1]))
     step = max(1, chunk_cells // plane)
@@ -215,6 +223,7 @@ def measure_fields_into(body, dims: Sequence[int], mu0, mu1, V, dsdf, t: float =
             xb = pts[:, bidx]
             sub = list(torch.unravel_index(bidx, shp))
             full = tuple(s + 1 for s in sub[:-1]) + (sub[-1] + (lo - kz0),)
+            cand.append(sum(f.to(torch.int64) * int(s) for f, s in zip(full, lstrides)))
             for i in range(D):
                 xf = xb.clone()
                 xf[i] -= 0.5                                  # face location loc(i,I) (util.jl:160)
@@ -224,6 +233,7 @@ def measure_fields_into(body, dims: Sequence[int], mu0, mu1, V, dsdf, t: float =
                 k1 = _mu1_t(di, eps)
                 for j in range(D):
                     mu1[full + (i, j)] = (k1 * ni[j]).to(tdt)
+    return torch.cat(cand) if cand else torch.zeros(0, dtype=torch.int64, device=dev)
 
 
 def _fortran_empty(shape, tdt):
@@ -248,16 +258,41 @@ def measure_fields(body, dims: Sequence[int], t: float = 0.0, eps: float = 1.0, 
     return m0.numpy(), m1.numpy(), Vv.numpy(), dd.numpy()
 
 
-def nds_band(body, dims: Sequence[int], t: float = 0.0, chunk_cells: int = 1 << 22, slab=None, device="cpu"):
+def nds_band(body, dims: Sequence[int], t: float = 0.0, chunk_cells: Optional[int] = None, slab=None, device="cpu",
+             candidates=None):
     """Metrics.jl:84-87 evaluated over inside(p): returns (idx, nds) where idx are the column-major
     linear indices (ghost-inclusive LOCAL extents) of cells with a non-zero n*kern(clamp(d,-1,1)) and nds is
     the (nband, D) Float64 array of those vectors (positions and normals in Float64, Metrics.jl:96).
-    Returned as numpy arrays; `device` only selects where the closures are evaluated."""
+    Returned as numpy arrays; `device` only selects where the closures are evaluated.
+    candidates (optional): local linear indices of a superset of the band (what measure_fields_into returned for the
+    same t): only those cells are examined instead of scanning the whole grid."""
     D = len(dims)
     Ng = tuple(int(n) + 2 for n in dims)
     strides = np.cumprod((1,) + Ng[:-1])
     if body is None or isinstance(body, NoBody):
         return np.zeros(0, dtype=np.int64), np.zeros((0, D))
+    if chunk_cells is None:
+        chunk_cells = (1 << 25) if torch.device(device).type == "cuda" else (1 << 22)
+    if candidates is not None:
+        kz0c = slab.kz0 if slab is not None else 0
+        cand = candidates.to(device)
+        if slab is not None:                       # owned interior planes only
+            kk = cand // int(strides[D - 1])
+            cand = cand[(kk >= slab.own_lo) & (kk <= slab.own_hi) & (kk + kz0c >= 1) & (kk + kz0c <= Ng[-1] - 2)]
+        if cand.numel() == 0:
+            return np.zeros(0, dtype=np.int64), np.zeros((0, D))
+        rem, coords = cand.clone(), []
+        for ddim in range(D - 1, -1, -1):
+            coords.insert(0, rem // int(strides[ddim]))
+            rem = rem % int(strides[ddim])
+        pts = torch.stack([c.to(torch.float64) - 0.5 for c in coords])
+        pts[D - 1] += kz0c
+        d, n, _ = measure(body, pts, t, fastd2=1.0)
+        v = (n * _kern_t(torch.clamp(d, -1, 1))[None]).T
+        keep = (v != 0).any(1)
+        idx, nds = cand[keep].cpu().numpy(), v[keep].cpu().numpy()
+        order = np.argsort(idx, kind="stable")
+        return idx[order], np.ascontiguousarray(nds[order])
     plane = int(np.prod(Ng[:-1]))
     step = max(1, chunk_cells // plane)
     idxs, vals = [], []
