@@ -194,6 +194,15 @@ int wl_mom_step(wl_flow *a, wl_mg *b, double dt, const double U[3], const double
 int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx_dev, const double *nds_dev,
               int64_t nband, double out[3]);
 
+/* viscous_force(u,nu,df,body,t)       src/Metrics.jl:109-113: out = sum_band Float64( T( -nu * (du_i/dx_j + du_j/dx_i) * nds ) ),
+ * same band hand-over as wl_pforce (idx are element offsets into one component of u). */
+int wl_vforce(wl_dtype t, const wl_grid *g, const void *u, const int64_t *idx_dev, const double *nds_dev, int64_t nband,
+              double nu, double out[3]);
+/* pressure_moment(x0,p,df,body,t)    src/Metrics.jl:130-134: out = sum_band Float64( T( p * cross(loc(0,I)-x0, nds) ) );
+ * D == 2: the scalar cross product is returned in every component, like the reference's broadcast. */
+int wl_pmoment(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx_dev, const double *nds_dev, int64_t nband,
+               const double x0[3], double out[3]);
+
 /* ------------------------------------------------------------------ tuning switches (A/B measurements)
  * key 0: 1 = use the 16-B-vectorised z-marching 7-point kernel where it applies (default), 0 = generic range kernel
  * key 1: 1 = fused V-cycle smoothers (default), 0 = the reference's two-pass Jacobi!/increment!/prolongate!

@@ -116,6 +116,8 @@ def _declare(L: C.CDLL) -> None:
         f("wlo_flow_create", vp, gp, vp, vp, vp, vp, vp, vp, vp, vp, d, i, i)
         f("wlo_flow_destroy", None, vp)
         f("wlo_pforce", None, vp, vp, gp, C.POINTER(C.c_long), dp, lg, dp)
+        f("wlo_vforce", None, vp, vp, gp, C.POINTER(C.c_long), dp, lg, d, dp)
+        f("wlo_pmoment", None, vp, vp, gp, C.POINTER(C.c_long), dp, lg, dp, dp)
         for nm in ("quick", "vanleer"):
             f("wlo_t_" + nm, d, d, d, d)
         f("wlo_t_phi", d, vp, lg)
@@ -483,6 +485,28 @@ def pressure_force_band(p: np.ndarray, df: np.ndarray, idx: np.ndarray, nds: np.
     return np.array(out[:D])
 
 
+def viscous_force_band(u: np.ndarray, nu: float, df: np.ndarray, idx: np.ndarray, nds: np.ndarray) -> np.ndarray:
+    """Metrics.jl:109-113 with the compact nds band"""
+    D = u.ndim - 1
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    nds = np.ascontiguousarray(nds, dtype=np.float64)
+    out = (C.c_double * 3)()
+    _fn("wlo_vforce", u.dtype)(_p(u), _p(df), C.byref(Grid.of(u.shape[:-1])), idx.ctypes.data_as(C.POINTER(C.c_long)),
+                               nds.ctypes.data_as(C.POINTER(C.c_double)), len(idx), float(nu), out)
+    return np.array(out[:D])
+
+
+def pressure_moment_band(x0, p: np.ndarray, df: np.ndarray, idx: np.ndarray, nds: np.ndarray) -> np.ndarray:
+    """Metrics.jl:130-134 with the compact nds band"""
+    D = p.ndim
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    nds = np.ascontiguousarray(nds, dtype=np.float64)
+    out = (C.c_double * 3)()
+    _fn("wlo_pmoment", p.dtype)(_p(p), _p(df), C.byref(Grid.of(p.shape)), idx.ctypes.data_as(C.POINTER(C.c_long)),
+                                nds.ctypes.data_as(C.POINTER(C.c_double)), len(idx), _d3(x0), out)
+    return np.array(out[:D])
+
+
 # --------------------------------------------------------------------------- WaterLily.jl
 
 class Simulation:
@@ -547,6 +571,20 @@ def pressure_force(sim: Simulation) -> np.ndarray:
     """Metrics.jl:94-95"""
     idx, nds = sim._nds_fn(sim.body, tuple(n - 2 for n in sim.flow.N), t=time(sim.flow))
     return pressure_force_band(sim.flow.p, sim.flow.f, idx, nds)
+
+
+def viscous_force(sim: Simulation) -> np.ndarray:
+    idx, nds = sim._nds_fn(sim.body, tuple(n - 2 for n in sim.flow.N), t=time(sim.flow))
+    return viscous_force_band(sim.flow.u, sim.flow.nu, sim.flow.f, idx, nds)
+
+
+def total_force(sim: Simulation) -> np.ndarray:
+    return pressure_force(sim) + viscous_force(sim)
+
+
+def pressure_moment(x0, sim: Simulation) -> np.ndarray:
+    idx, nds = sim._nds_fn(sim.body, tuple(n - 2 for n in sim.flow.N), t=time(sim.flow))
+    return pressure_moment_band(x0, sim.flow.p, sim.flow.f, idx, nds)
 
 
 # known-answer access to the scalar stencil helpers (Flow.jl:3-9)

@@ -770,6 +770,64 @@ void SUF(wlo_pforce)(const T *p, T *df, const wlo_grid *g, const long *idx, cons
     }
 }
 
+/* Metrics.jl:28-31  d u_i / d x_j at the cell centre, in T */
+static inline T SUF(dudx)(const T *u, const wlo_grid *g, long I, int i, int j) {
+    const T *ui = u + (long)i * g->ncell;
+    if (i == j) return ui[I + g->s[i]] - ui[I];
+    return (ui[I + g->s[j]] + ui[I + g->s[j] + g->s[i]] - ui[I - g->s[j]] - ui[I - g->s[j] + g->s[i]]) / (T)4;
+}
+/* Metrics.jl:109-113 viscous_force: df[I,:] = -nu*grad2u(I,u)*nds (Float32 matrix times Float64 vector), stored in the
+ * T array df, summed in Float64.  nds comes as the same compact band as for wlo_pforce. */
+void SUF(wlo_vforce)(const T *u, T *df, const wlo_grid *g, const long *idx, const double *nds, long nband, double nu_,
+                     double *out) {
+    const int D = g->D;
+    const long nc = g->ncell;
+    const T nu = (T)nu_;
+    for (long q = 0; q < nc * D; ++q) df[q] = 0;
+    for (long b = 0; b < nband; ++b)
+        for (int i = 0; i < D; ++i) {
+            double s = 0;
+            for (int j = 0; j < D; ++j) {
+                const T m = -nu * (T)(SUF(dudx)(u, g, idx[b], i, j) + SUF(dudx)(u, g, idx[b], j, i));
+                s += (double)m * nds[b * D + j];
+            }
+            df[idx[b] + i * nc] = (T)s;
+        }
+    for (int c = 0; c < D; ++c) {
+        double s = 0;
+        for (long b = 0; b < nband; ++b) s += (double)df[idx[b] + c * nc];
+        out[c] = s;
+    }
+}
+/* Metrics.jl:130-134 pressure_moment: df[I,:] = p[I]*cross(loc(0,I)-x0, nds) */
+void SUF(wlo_pmoment)(const T *p, T *df, const wlo_grid *g, const long *idx, const double *nds, long nband,
+                      const double *x0, double *out) {
+    const int D = g->D;
+    const long nc = g->ncell;
+    for (long q = 0; q < nc * D; ++q) df[q] = 0;
+    for (long b = 0; b < nband; ++b) {
+        const long I = idx[b];
+        const long k = D > 2 ? I / g->s[2] : 0, rem = D > 2 ? I - k * g->s[2] : I;
+        const long j = rem / g->s[1], i = rem - j * g->s[1];
+        const double rx = (double)i - 0.5 - x0[0], ry = (double)j - 0.5 - x0[1], rz = D > 2 ? (double)k - 0.5 - x0[2] : 0.0;
+        const double pv = (double)p[I];
+        if (D == 3) {
+            const double nx = nds[b * 3], ny = nds[b * 3 + 1], nz = nds[b * 3 + 2];
+            df[I] = (T)(pv * (ry * nz - rz * ny));
+            df[I + nc] = (T)(pv * (rz * nx - rx * nz));
+            df[I + 2 * nc] = (T)(pv * (rx * ny - ry * nx));
+        } else {
+            const T m = (T)(pv * (rx * nds[b * 2 + 1] - ry * nds[b * 2]));
+            df[I] = m; df[I + nc] = m;
+        }
+    }
+    for (int c = 0; c < D; ++c) {
+        double s = 0;
+        for (long b = 0; b < nband; ++b) s += (double)df[idx[b] + c * nc];
+        out[c] = s;
+    }
+}
+
 /* known-answer helpers exported for tests/test_oracle_pins.py */
 double SUF(wlo_t_quick)(double u, double c, double d) { return (double)SUF(quick)((T)u, (T)c, (T)d); }
 double SUF(wlo_t_vanleer)(double u, double c, double d) { return (double)SUF(vanleer)((T)u, (T)c, (T)d); }

@@ -466,3 +466,39 @@ def test_noncubic_partial_tiles(T):
     body = AutoBody(lambda x, t: norm2(x - (m / 2 - 1)) - R)
     so, sh = pair((96, m, m), (1.0, 0.0, 0.0), 2 * R, nu=2 * R / 250, body=body, T=T)
     check_step(so, sh, T, 2)
+
+
+@pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("D", [2, 3])
+def test_viscous_force_pressure_moment_parity(T, D):
+    """Metrics.jl:103-134 on random fields: HIP band kernels vs the oracle."""
+    N = 32
+    shp = (N,) * D
+    body = AutoBody(lambda x, t: norm2(x - N / 2) - N // 4)
+    idx, nds = B.nds_band(body, tuple(n - 2 for n in shp))
+    u, p = rnd(shp + (D,), T, 70), rnd(shp, T, 71)
+    df = O.zeros(shp + (D,), T)
+    ud, pd = field(u, D), field(p, D)
+    bi, bn = S.band_to_device(pd, idx, nds)
+    g = S._grid_of(ud, D)
+    out = (S.C.c_double * 3)()
+    S.check(S._lib.lib().wl_vforce(S._WLT[np.dtype(T)], S.C.byref(g), S._ptr(ud), S.C.c_void_p(bi.data_ptr()),
+                                   S.C.c_void_p(bn.data_ptr()), bi.numel(), 0.37, out))
+    ref = O.viscous_force_band(u, 0.37, df, idx, nds)
+    assert np.allclose(np.array(out[:D]), ref, rtol=1e-12, atol=1e-12)
+    x0 = (N / 2 + 0.25, N / 2 - 1.0, N / 2)[:D]
+    S.check(S._lib.lib().wl_pmoment(S._WLT[np.dtype(T)], S.C.byref(S._grid_of(pd, D)), S._ptr(pd), S.C.c_void_p(bi.data_ptr()),
+                                    S.C.c_void_p(bn.data_ptr()), bi.numel(), S.d3(x0), out))
+    ref = O.pressure_moment_band(x0, p, df, idx, nds)
+    assert np.allclose(np.array(out[:D]), ref, rtol=1e-12, atol=1e-10)
+
+
+def test_total_force_api():
+    m = 32
+    R = m / 8
+    body = AutoBody(lambda x, t: norm2(x - (m / 2 - 1)) - R)
+    so, sh = pair((m, m, m), (1.0, 0.0, 0.0), 2 * R, nu=2 * R / 100, body=body, T=np.float64)
+    check_step(so, sh, np.float64, 2)
+    assert np.allclose(S.viscous_force(sh), O.viscous_force(so), rtol=1e-8, atol=1e-12)
+    assert np.allclose(S.total_force(sh), O.total_force(so), rtol=1e-8, atol=1e-12)
+    assert np.allclose(S.pressure_moment((m / 2,) * 3, sh), O.pressure_moment((m / 2,) * 3, so), rtol=1e-7, atol=1e-9)

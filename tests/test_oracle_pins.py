@@ -325,3 +325,23 @@ def test_moving_bodies(exitBC):  # :391-412
     O.sim_step(s)
     assert s.pois.n == [2, 1]
     assert 1.2 > s.flow.dt[-1] > 0.8
+
+
+# ----------------------------------------------------------------------------- Metrics.jl viscous force / moment (:360-368)
+
+def test_viscous_force_and_pressure_moment():
+    N = 32
+    for D in (2, 3):
+        shp = (N,) * D
+        body = AutoBody(lambda x, t: norm2(x - N / 2) - N // 4)
+        idx, nds = B.nds_band(body, tuple(n - 2 for n in shp))
+        u = O.zeros(shp + (D,), np.float64)
+        df = O.zeros(shp + (D,), np.float64)
+        assert np.allclose(O.viscous_force_band(u, 1.0, df, idx, nds), 0)                       # :362-363
+        O.apply_vec(lambda i, x: x[i], u)                                                        # uniform dilatation:
+        f = O.viscous_force_band(u, 1.0, df, idx, nds)                                           # -nu*2I*oint(n ds) = 0
+        assert np.allclose(f, 0, atol=1e-9)
+        p = O.zeros(shp, np.float64)
+        O.apply_scalar(lambda x: x[1], p)
+        m = O.pressure_moment_band((N / 2,) * D, p, df, idx, nds)                                # :365-368
+        assert np.allclose(m, 0, atol=1e-8 * N ** D)

@@ -123,6 +123,8 @@ def lib() -> C.CDLL:
         "wl_project": (i, [vp, vp, d, d, ip]),
         "wl_mom_step": (i, [vp, vp, d, dp, dp, dp, dp, ip]),
         "wl_pforce": (i, [i, gp, vp, vp, vp, i64, dp]),
+        "wl_vforce": (i, [i, gp, vp, vp, vp, i64, d, dp]),
+        "wl_pmoment": (i, [i, gp, vp, vp, vp, i64, dp, dp]),
         "wl_set_option": (i, [i, i]),
         "wl_kernel_name": (C.c_char_p, [i]),
         "wl_prof_select": (i, [i, i64]),

@@ -329,6 +329,59 @@ static int bdim_full(const G &g, T *u, const T *u0, T *f, const T *V, const T *m
     WL_TRY((op_bdim1<T, D>(g, f, u0, V, dt)));
     return op_bdim2<T, D, 0>(g, u, f, V, mu0, mu1);
 }
+// du_i/dx_j at the centre of cell I (src/Metrics.jl:28-31), in T
+template <class T> __device__ inline T dudx(const G &g, const T *u, long I, int i, int j) {
+    const T *ui = u + (long)i * g.sc;
+    if (i == j) return ui[I + g.s[i]] - ui[I];
+    return (ui[I + g.s[j]] + ui[I + g.s[j] + g.s[i]] - ui[I - g.s[j]] - ui[I - g.s[j] + g.s[i]]) / (T)4;
+}
+// Metrics.jl:109-113 viscous_force over the band
+template <class T>
+__global__ __launch_bounds__(256) void k_vforce(G g, const T *u, const int64_t *idx, const double *nds, int64_t nband, T nu,
+                                                double *partials) {
+    double acc[3] = {0, 0, 0};
+    const int D = g.D;
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nband; b += (int64_t)gridDim.x * 256) {
+        const long I = idx[b];
+        for (int i = 0; i < D; ++i) {
+            double s = 0;
+            for (int j = 0; j < D; ++j) {
+                const T m = -nu * (T)(dudx<T>(g, u, I, i, j) + dudx<T>(g, u, I, j, i));   // (-nu * grad2u)[i,j] in T
+                s += (double)m * nds[b * D + j];
+            }
+            acc[i] += (double)(T)s;                                                        // df[I,:] is a T array
+        }
+    }
+    block_red<3>(acc, RED_SUM);
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; ++c) partials[(long)c * gridDim.x + blockIdx.x] = acc[c];
+}
+// Metrics.jl:130-134 pressure_moment over the band
+template <class T>
+__global__ __launch_bounds__(256) void k_pmoment(G g, const T *p, const int64_t *idx, const double *nds, int64_t nband,
+                                                 double x0, double y0, double z0, double *partials) {
+    double acc[3] = {0, 0, 0};
+    const int D = g.D;
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nband; b += (int64_t)gridDim.x * 256) {
+        const long I = idx[b];
+        const long k = D > 2 ? I / g.s[2] : 0, rem = D > 2 ? I - k * g.s[2] : I;
+        const long j = rem / g.s[1], i = rem - j * g.s[1];
+        const double rx = (double)i - 0.5 - x0, ry = (double)j - 0.5 - y0, rz = (double)(k + g.kz0) - 0.5 - z0;  // loc(0,I)-x0
+        const double pv = (double)p[I];
+        if (D == 3) {
+            const double nx = nds[b * 3], ny = nds[b * 3 + 1], nz = nds[b * 3 + 2];
+            acc[0] += (double)(T)(pv * (ry * nz - rz * ny));
+            acc[1] += (double)(T)(pv * (rz * nx - rx * nz));
+            acc[2] += (double)(T)(pv * (rx * ny - ry * nx));
+        } else {
+            const double m = (double)(T)(pv * (rx * nds[b * 2 + 1] - ry * nds[b * 2]));
+            acc[0] += m; acc[1] += m;
+        }
+    }
+    block_red<3>(acc, RED_SUM);
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; ++c) partials[(long)c * gridDim.x + blockIdx.x] = acc[c];
+}
 template <class T>
 __global__ __launch_bounds__(256) void k_pforce(const T *p, const int64_t *idx, const double *nds, int64_t nband, int D,
                                                  double *partials) {
@@ -345,6 +398,24 @@ template <class T, int D> static int flow_update(wl_flow *a) {
     const G g = mkG(&a->d.g);
     WL_TRY((op_rowflags<T, D>(g, (const T *)a->d.V, (const T *)a->d.mu0, (const T *)a->d.mu1, a->rowbuf, a->d.perdir_mask)));
     a->rowfree = a->rowbuf;
+    return 0;
+}
+// shared driver of the band reductions (pressure_force / viscous_force / pressure_moment)
+template <class KERNEL> static int band_reduce(const G &gg, Scratch &S, int64_t nband, int D, double out[3], KERNEL launch) {
+    out[0] = out[1] = out[2] = 0;
+    int nb = (int)((nband + 255) / 256);
+    if (nb > 1024) nb = 1024;
+    if (nband <= 0) nb = 0;   // a rank whose slab holds no part of the body still joins the all-reduce
+    if (nb > 0) {
+        Prof pr(WL_K_PFORCE, nband);
+        launch(nb);
+        WL_HIP(hipGetLastError());
+    }
+    State *st = S.st;
+    WL_TRY((launch_finalize<3>(gg.dist, S.partials, nb, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
+        st->out[0] = v[0]; st->out[1] = v[1]; st->out[2] = v[2]; })));
+    WL_TRY(S.fetch());
+    for (int c = 0; c < D; ++c) out[c] = S.hst->out[c];
     return 0;
 }
 template <class T, int D> static int restrictL_full(const G &A, T *a, const G &B, const T *b, int permask) {
@@ -667,6 +738,23 @@ int wl_mom_step(wl_flow *a, wl_mg *b, double dt, const double U[3], const double
 }
 
 // ---- Metrics.jl:94-100
+int wl_vforce(wl_dtype t, const wl_grid *g, const void *u, const int64_t *idx, const double *nds, int64_t nband, double nu,
+              double out[3]) {
+    WL_GS();
+    return band_reduce(gg, S, nband, g->D, out, [&](int nb) {
+        if (t == WL_F32) hipLaunchKernelGGL(k_vforce<float>, dim3(nb), dim3(256), 0, ctx().stream, gg, (const float *)u, idx, nds, nband, (float)nu, S.partials);
+        else hipLaunchKernelGGL(k_vforce<double>, dim3(nb), dim3(256), 0, ctx().stream, gg, (const double *)u, idx, nds, nband, nu, S.partials);
+    });
+}
+int wl_pmoment(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx, const double *nds, int64_t nband,
+               const double x0[3], double out[3]) {
+    WL_GS();
+    const double a = x0[0], b = x0[1], c = g->D > 2 ? x0[2] : 0.0;
+    return band_reduce(gg, S, nband, g->D, out, [&](int nb) {
+        if (t == WL_F32) hipLaunchKernelGGL(k_pmoment<float>, dim3(nb), dim3(256), 0, ctx().stream, gg, (const float *)p, idx, nds, nband, a, b, c, S.partials);
+        else hipLaunchKernelGGL(k_pmoment<double>, dim3(nb), dim3(256), 0, ctx().stream, gg, (const double *)p, idx, nds, nband, a, b, c, S.partials);
+    });
+}
 int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx, const double *nds, int64_t nband,
               double out[3]) {
     WL_GS();

@@ -670,12 +670,49 @@ def band_to_device(p: torch.Tensor, idx: np.ndarray, nds: np.ndarray):
             torch.from_numpy(np.ascontiguousarray(nds, dtype=np.float64)).to(p.device))
 
 
+def _band_of(sim: Simulation):
+    """(idx, nds) device tensors of the |d|<=1 band at the current flow time (cached per time)"""
+    _ensure_band(sim)
+    return sim._band[1], sim._band[2]
+
+
+def viscous_force(sim: Simulation) -> np.ndarray:
+    """Metrics.jl:108-113"""
+    idx, nds = _band_of(sim)
+    u = sim.flow.u
+    out = (C.c_double * 3)()
+    g = _grid_of(u, u.ndim - 1)
+    check(_lib.lib().wl_vforce(_WLT[_T(u)], C.byref(g), _ptr(u), C.c_void_p(idx.data_ptr()), C.c_void_p(nds.data_ptr()),
+                               idx.numel(), sim.flow.nu, out))
+    return np.array(out[:sim.flow.D])
+
+
+def total_force(sim: Simulation) -> np.ndarray:
+    """Metrics.jl:120"""
+    return pressure_force(sim) + viscous_force(sim)
+
+
+def pressure_moment(x0, sim: Simulation) -> np.ndarray:
+    """Metrics.jl:128-134"""
+    idx, nds = _band_of(sim)
+    p = sim.flow.p
+    out = (C.c_double * 3)()
+    g = _grid_of(p, p.ndim)
+    check(_lib.lib().wl_pmoment(_WLT[_T(p)], C.byref(g), _ptr(p), C.c_void_p(idx.data_ptr()), C.c_void_p(nds.data_ptr()),
+                                idx.numel(), d3(x0), out))
+    return np.array(out[:sim.flow.D])
+
+
 def pressure_force(sim: Simulation) -> np.ndarray:
     """Metrics.jl:94-95"""
+    _ensure_band(sim)
+    return pressure_force_band(sim.flow.p, sim._band[1], sim._band[2])
+
+
+def _ensure_band(sim: Simulation) -> None:
     if sim._band is None or sim._band[0] != time(sim.flow):
         bc = getattr(sim.flow, "_band_cells", None)
         cand = bc[1] if (bc is not None and abs(bc[0] - time(sim.flow)) <= 1e-12 * max(1.0, abs(bc[0]))) else None
         idx, nds = B.nds_band(sim.body, tuple(n - 2 for n in sim.flow.N), t=time(sim.flow), slab=sim.slab,
                               device=sim.flow.device if sim.geometry == "device" else "cpu", candidates=cand)
         sim._band = (time(sim.flow),) + band_to_device(sim.flow.p, idx, nds)
-    return pressure_force_band(sim.flow.p, sim._band[1], sim._band[2])
