@@ -191,6 +191,9 @@ struct wl_flow {
     Scratch sc;
     unsigned char *rowfree = nullptr;   // body-free row flags (wl_flow_update); nullptr until built
     unsigned char *rowbuf = nullptr;
+    int *busy = nullptr;                // compact list of the busy interior rows (j + n1*k), device
+    int nbusy = 0;
+    size_t busy_cap = 0;
 };
 
 template <class T> static LevelT<T> lvl(const wl_mg *m, int l) {
@@ -249,8 +252,8 @@ template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, in
     int n = 0;
     while (n < itmx) {
         if (m->nlev > 1) WL_TRY((mg_vcycle<T, D>(m, 0)));
-        WL_TRY((op_pcg<T, D>(p, 6, m->permask, m->sc.partials, m->sc.st)));
-        WL_TRY((op_L2<T, D>(p, m->sc.partials, m->sc.st)));
+        WL_TRY((op_pcg<T, D>(p, 6, m->permask, m->sc.partials, m->sc.st, true)));
+        WL_TRY((op_L2<T, D>(p, m->sc.partials, m->sc.st, true)));
         WL_TRY(m->sc.fetch());
         ++n;
         if (m->sc.hst->r2 < tol) break;
@@ -287,7 +290,7 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     // (z-slab runs: u carries a 2-plane halo for QUICK, f a 1-plane halo for mu_ddn; exchanges are no-ops otherwise)
     WL_TRY((op_conv_diff<T, D, true, true>(g, f, u, d.nu, d.perdir_mask, nullptr, V, dt, gp, gp != nullptr, u0)));
     WL_TRY((halo_exchange<T>(g, f, D, 1)));
-    WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree)));
+    WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, u, u0, U, dt, a->sc.partials, a->sc.st)));
     WL_TRY((halo_exchange<T>(g, u, D, 1)));
@@ -297,7 +300,7 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     // corrector (:164-167)
     WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr)));
     WL_TRY((halo_exchange<T>(g, f, D, 1)));
-    WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree)));
+    WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     WL_TRY((halo_exchange<T>(g, u, D, 1)));
     WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1])));
@@ -398,6 +401,25 @@ template <class T, int D> static int flow_update(wl_flow *a) {
     const G g = mkG(&a->d.g);
     WL_TRY((op_rowflags<T, D>(g, (const T *)a->d.V, (const T *)a->d.mu0, (const T *)a->d.mu1, a->rowbuf, a->d.perdir_mask)));
     a->rowfree = a->rowbuf;
+    // compact the busy INTERIOR rows on the host (n1*n2 bytes; this runs once per measure!, not per step)
+    const size_t nrows = (size_t)g.n[1] * (size_t)(D > 2 ? g.n[2] : 1);
+    std::vector<unsigned char> fl(nrows);
+    WL_HIP(hipMemcpyAsync(fl.data(), a->rowbuf, nrows, hipMemcpyDeviceToHost, ctx().stream));
+    WL_HIP(hipStreamSynchronize(ctx().stream));
+    const Range R = r_inside(g);
+    std::vector<int> list;
+    for (int k = R.lo[2]; k <= R.hi[2]; ++k)
+        for (int j = 1; j <= g.n[1] - 2; ++j)
+            if (!fl[(size_t)j + (size_t)g.n[1] * k]) list.push_back(j + g.n[1] * k);
+    if (list.size() > a->busy_cap) {
+        if (a->busy) (void)hipFree(a->busy);
+        a->busy_cap = list.size() * 2 + 64;
+        WL_HIP(hipMalloc((void **)&a->busy, a->busy_cap * sizeof(int)));
+    }
+    if (!a->busy) { a->busy_cap = 64; WL_HIP(hipMalloc((void **)&a->busy, a->busy_cap * sizeof(int))); }
+    if (!list.empty()) WL_HIP(hipMemcpyAsync(a->busy, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, ctx().stream));
+    WL_HIP(hipStreamSynchronize(ctx().stream));
+    a->nbusy = (int)list.size();
     return 0;
 }
 // shared driver of the band reductions (pressure_force / viscous_force / pressure_moment)
@@ -708,6 +730,7 @@ int wl_flow_destroy(wl_flow *a) {
     (void)hipStreamSynchronize(ctx().stream);
     a->sc.release();
     if (a->rowbuf) (void)hipFree(a->rowbuf);
+    if (a->busy) (void)hipFree(a->busy);
     delete a;
     return 0;
 }

@@ -22,7 +22,7 @@ struct State {
     int active;               // pcg still running
     int do_shift;             // residual! must subtract the mean
     int nupd;                 // number of (x,r) updates pcg performed
-    int pad;
+    int r2_valid;             // the last pcg! update already produced r.r (solver! can skip the separate L2 pass)
 };
 
 template <class T> struct LevelT {
@@ -258,15 +258,80 @@ _Pragma("unroll")
 // second BDIM! loop  src/Flow.jl:134 with mu_ddn (:18-24).  MODE 0: u += ...  (the reference statement)
 // MODE 1: predictor, u was zeroed by scale_u!(a,0) (:154) -> u = ... ; MODE 2: corrector, followed by
 // scale_u!(a,0.5) (:166) -> u = 0.5*(u + ...), both roundings kept.
+// general BDIM! statement on a compact list of rows (row = j + n1*k), one wavefront per 64-cell row segment
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *f, const T *V, const T *mu0, const T *mu1,
+                                                    const int *rows, int nrows, int ntx) {
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long)nrows * ntx) return;
+    const int row = rows[w / ntx];
+    const int i = 1 + (int)(w % ntx) * 64 + (threadIdx.x & 63);
+    if (i > g.n[0] - 2) return;
+    const int j = row % g.n[1], k = row / g.n[1];
+    const long I = g.at(i, j, k);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const T *fc = f + (long)c * g.sc;
+        T s = 0;
+#pragma unroll
+        for (int jd = 0; jd < 3; ++jd) {
+            const T *m1 = mu1 + (long)(c + 3 * jd) * g.sc;
+            s += m1[I] * (fc[I + g.s[jd]] - fc[I - g.s[jd]]);
+        }
+        const long q = I + (long)c * g.sc;
+        const double tmp = (0.5 * (double)s + (double)V[q]) + (double)(T)(mu0[q] * fc[I]);
+        if (MODE == 1) u[q] = (T)(0.0 + tmp);
+        else { const T un = (T)((double)u[q] + tmp); u[q] = (MODE == 2) ? (T)((double)un * 0.5) : un; }
+    }
+}
+
 // `rowfree` (optional, mom_step! only): rowfree[j + n1*k] != 0 means mu1 == 0, V == 0 and mu0 == 1 on x-row (j,k), so
 // the statement reduces to u (+)= f -- same value, 15 coefficient reads and 6 neighbour reads per cell skipped.
 template <class T, int D, int MODE>
-int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu1, const unsigned char *rowfree = nullptr) {
+int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu1, const unsigned char *rowfree = nullptr,
+             const int *busy = nullptr, int nbusy = 0) {
     const G gg = g;
     if (!ctx().opt[3]) rowfree = nullptr;
+    bool skip_free = false;   // the free rows were already done by the vector pass
+    if constexpr (D == 3) {
+        // two passes: (1) 16-B vector kernel streams u (+)= f on the body-free rows, (2) the scalar range kernel below
+        // evaluates the general statement on the busy rows only (coalesced per cell; ~5 % of the rows for a sphere)
+        if (rowfree && stencil7_ok<T>(g, u, f)) {
+            using VA = VecA<T>;
+            const int rc = launch_rowvec<T, 0>(WL_K_BDIM, g, [=] __device__(long o, int j, int k, double *) {
+                if (!rowfree[j + gg.n[1] * k]) return;
+_Pragma("unroll")
+                for (int c = 0; c < 3; ++c) {
+                    const long q = o + (long)c * gg.sc;
+                    const VA fv = VA::load(f + q);
+                    VA uv;
+                    if (MODE != 1) uv = VA::load(u + q);
+_Pragma("unroll")
+                    for (int v = 0; v < VA::V; ++v) {
+                        const double tmp = (0.5 * 0.0 + 0.0) + (double)fv.v[v];
+                        if (MODE == 1) uv.v[v] = (T)(0.0 + tmp);
+                        else { const T un = (T)((double)uv.v[v] + tmp); uv.v[v] = (MODE == 2) ? (T)((double)un * 0.5) : un; }
+                    }
+                    uv.store(u + q);
+                }
+            }, nullptr, nullptr);
+            if (rc > 0) return rc;
+            if (rc == 0) skip_free = true;
+            if (skip_free && busy) {   // compact list of busy interior rows (built by wl_flow_update): touch only those
+                if (nbusy == 0) return 0;
+                const int ntx = (g.n[0] - 2 + 63) / 64;
+                const long nw = (long)nbusy * ntx;
+                Prof p(WL_K_BDIM, (long)nbusy * (g.n[0] - 2));
+                hipLaunchKernelGGL((k_bdim2_busy<T, MODE>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx().stream, g, u, f, V,
+                                   mu0, mu1, busy, nbusy, ntx);
+                return (int)hipGetLastError();
+            }
+        }
+    }
     return launch_range(WL_K_BDIM, r_inside(g), [=] __device__(int i, int j, int k) {
         const long I = gg.at(i, j, k);
         if (rowfree && rowfree[j + gg.n[1] * k]) {   // wave-uniform: a wavefront never spans two rows
+            if (skip_free) return;
 _Pragma("unroll")
             for (int c = 0; c < D; ++c) {
                 const long q = I + (long)c * gg.sc;
@@ -668,8 +733,9 @@ _Pragma("unroll")
 // pcg!  src/Poisson.jl:123-143 with device-resident rho/alpha/beta and the four early exits turned into a
 // device flag: once `active` drops, the remaining (already enqueued) kernels are no-ops, so no host sync.
 // Fusions: [mult + z.eps], [x,r update + z=r*iD + r.z], [direction]; identical per-cell arithmetic.
+// want_r2: the caller (solver!) needs L2(p) = r.r right after this call; it is accumulated by the last update kernel.
 template <class T, int D>
-int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st) {
+int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st, bool want_r2 = false) {
     const LevelT<T> q = p;
     const Range R = r_inside(p.g);
     const T eps10 = (T)10 * Lim<T>::eps;
@@ -682,7 +748,7 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st)
     // :125-127
     int rv0 = -1;
     if (vec) {
-        rv0 = launch_rowvec<T, 1>(WL_K_PCG_INIT, p.g, [=] __device__(long o, double *acc) {
+        rv0 = launch_rowvec<T, 1>(WL_K_PCG_INIT, p.g, [=] __device__(long o, int, int, double *acc) {
             const VA rr = VA::load(q.r + o), id = VA::load(q.iD + o);
             VA zv;
 _Pragma("unroll")
@@ -703,6 +769,7 @@ _Pragma("unroll")
         const T rho = (T)v[0];
         st->rho = (double)rho;
         st->nupd = 0;
+        st->r2_valid = 0;
         st->active = !((rho < 0 ? -rho : rho) < eps10);
     })));
     for (int n = 1; n <= it; ++n) {
@@ -740,7 +807,7 @@ _Pragma("unroll")
         // :133-137
         int rvu = -1;
         if (vec) {
-            rvu = launch_rowvec<T, 1>(WL_K_PCG_UPDATE, p.g, [=] __device__(long o, double *acc) {
+            rvu = launch_rowvec<T, 1>(WL_K_PCG_UPDATE, p.g, [=] __device__(long o, int, int, double *acc) {
                 if (!st->active) return;
                 const T alpha = (T)st->alpha;
                 VA xv = VA::load(q.x + o), rr = VA::load(q.r + o);
@@ -755,6 +822,9 @@ _Pragma("unroll")
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) { zn.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zn.v[v]; }
                     zn.store(q.z + o);
+                } else if (want_r2) {
+_Pragma("unroll")
+                    for (int v = 0; v < VA::V; ++v) acc[0] += (double)rr.v[v] * (double)rr.v[v];
                 }
             }, partials, &np);
             if (rvu > 0) return rvu;
@@ -771,12 +841,18 @@ _Pragma("unroll")
                 const T zn = rn * q.iD[I];
                 q.z[I] = zn;
                 acc[0] += (double)rn * (double)zn;
+            } else if (want_r2) {
+                acc[0] += (double)rn * (double)rn;
             }
         }, partials, RED_SUM, 0.0, &np)));
         WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
             if (!st->active) return;
             st->nupd += 1;
-            if (last) { st->active = 0; return; }  // :135
+            if (last) {  // :135
+                if (want_r2) { st->r2 = (double)(T)v[0]; st->r2_valid = 1; }
+                st->active = 0;
+                return;
+            }
             const T rho2 = (T)v[0];
             if ((rho2 < 0 ? -rho2 : rho2) < eps10) { st->active = 0; return; }  // :138
             st->beta = (double)(rho2 / (T)st->rho);
@@ -786,7 +862,7 @@ _Pragma("unroll")
         // :140
         int rvd = -1;
         if (vec) {
-            rvd = launch_rowvec<T, 0>(WL_K_PCG_DIR, p.g, [=] __device__(long o, double *) {
+            rvd = launch_rowvec<T, 0>(WL_K_PCG_DIR, p.g, [=] __device__(long o, int, int, double *) {
                 if (!st->active) return;
                 const T beta = (T)st->beta;
                 VA ev = VA::load(q.eps + o);
@@ -807,16 +883,21 @@ _Pragma("unroll")
     return 0;
 }
 
-// L2(p) = r.r  src/Poisson.jl:146 -> st->r2
+// L2(p) = r.r  src/Poisson.jl:146 -> st->r2.  after_pcg: skip the work when the pcg! call just before already
+// produced it (st->r2_valid, see op_pcg want_r2); the kernels are still enqueued (no host decision) but return at once.
 template <class T, int D>
-int op_L2(const LevelT<T> &p, double *partials, State *st) {
+int op_L2(const LevelT<T> &p, double *partials, State *st, bool after_pcg = false) {
     const LevelT<T> q = p;
     int np = 0;
     WL_TRY((launch_range_red<1>(WL_K_DOT, r_inside(p.g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
+        if (after_pcg && st->r2_valid) return;
         const double v = (double)q.r[q.g.at(i, j, k)];
         acc[0] += v * v;
     }, partials, RED_SUM, 0.0, &np)));
-    return launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) { st->r2 = (double)(T)v[0]; });
+    return launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
+        if (after_pcg && st->r2_valid) return;
+        st->r2 = (double)(T)v[0];
+    });
 }
 
 // ------------------------------------------------------------------------------------------ MultiLevelPoisson.jl

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__r
     }
 }
 
-// ---- 16-B vectorised streaming (no neighbours): f(o, acc) is called once per V-cell vector at element offset o.
+// ---- 16-B vectorised streaming (no neighbours): f(o, j, k, acc) is called once per V-cell vector at element offset o.
 // Same row mapping as k_stencil7 (lane = V cells of a row, wavefront = row segment, workgroup = 4 rows marching in z).
 template <class T, int NRED, class F>
 __global__ __launch_bounds__(256) void k_rowvec(G g, F f, double *partials, int ntx, int tpp, int nblk, int clen, int klo,
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, F f, double *partials, int 
     for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) acc[q] = 0.0;
     if (i <= g.n[0] - 2 && j <= g.n[1] - 2) {
         const long col = (long)i + g.s[1] * (long)j;
-        for (int k = k0; k < k1; ++k) f(col + g.s[2] * k, acc);
+        for (int k = k0; k < k1; ++k) f(col + g.s[2] * k, j, k, acc);
     }
     if (NRED > 0) {
         block_red<(NRED > 0 ? NRED : 1), 4>(acc, RED_SUM);
