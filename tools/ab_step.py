@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""In-process A/B of whole sim_step! time for one wl_set_option key.  usage: ab_step.py <size> <key> [reps]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from waterlily_amd import _lib, sim as S
+size, key = int(sys.argv[1]), int(sys.argv[2])
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+L = _lib.lib()
+sim = bench.sphere((size,) * 3, np.float32)
+for _ in range(6):
+    S.sim_step(sim, remeasure=False)
+res = {0: [], 1: []}
+for r in range(reps):
+    for val in (1, 0):
+        _lib.check(L.wl_set_option(key, val))
+        S.sim_step(sim, remeasure=False); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            S.sim_step(sim, remeasure=False)
+        torch.cuda.synchronize()
+        res[val].append((time.perf_counter() - t0) / 5 * 1e3)
+for val in (1, 0):
+    print(f"{size}^3 option[{key}]={val}: median {np.median(res[val]):.3f} ms/step  (all: {[round(x, 2) for x in res[val]]})  n={sim.pois.n[-2:]}")

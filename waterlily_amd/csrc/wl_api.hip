@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include "wl_ops.h"
+#include "wl_coarse.h"
 
 namespace wl {
 
@@ -237,8 +238,25 @@ template <class T, int D> static int mg_vcycle(wl_mg *m, int l) {
         Prof p(WL_K_MISC, coarse.g.cells());
         WL_HIP(hipMemsetAsync(coarse.x, 0, (size_t)span(coarse.g) * sizeof(T), ctx().stream));
     }
-    if (l + 2 < m->nlev) WL_TRY((mg_vcycle<T, D>(m, l + 1)));
-    WL_TRY((op_pcg<T, D>(coarse, 6, m->permask, m->sc.partials, m->sc.st)));
+    // levels <= 4096 cells: the rest of the recursion + smooth!(coarse) as ONE single-workgroup launch (wl_coarse.h)
+    bool tail = ctx().opt[6] && fused && !coarse.g.dist && coarse.g.interior_cells() <= CV_MAXCELLS && (m->nlev - (l + 1)) <= CV_MAXLEV;
+    if (tail) {
+        CoarseArgs<T> ca;
+        ca.nlev = m->nlev - (l + 1);
+        for (int q = 0; q < ca.nlev; ++q) {
+            ca.lev[q] = lvl<T>(m, l + 1 + q);
+            if (ca.lev[q].g.dist) tail = false;
+        }
+        if (tail) {
+            Prof p(WL_K_SMOOTH, coarse.g.cells());
+            hipLaunchKernelGGL((k_coarse_vcycle<T, D>), dim3(1), dim3(CV_THREADS), 0, ctx().stream, ca);
+            WL_HIP(hipGetLastError());
+        }
+    }
+    if (!tail) {
+        if (l + 2 < m->nlev) WL_TRY((mg_vcycle<T, D>(m, l + 1)));
+        WL_TRY((op_pcg<T, D>(coarse, 6, m->permask, m->sc.partials, m->sc.st)));
+    }
     if (fused) return op_prolong_increment_fused<T, D>(fine, fine.eps, coarse.g, coarse.x);
     WL_TRY((op_prolongate<T, D>(fine.g, fine.eps, coarse.g, coarse.x)));
     return op_increment<T, D>(fine, m->permask);
