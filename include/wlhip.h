@@ -210,6 +210,7 @@ int wl_pmoment(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx_d
  * key 3: 1 = BDIM! uses the body-free row flags (default), 0 = general path everywhere
  * key 5: 1 = 16-B vectorised streaming pcg kernels (update/direction/init; default), 0 = scalar range kernels
  * key 6: 1 = multigrid levels <= 4096 cells run as one single-workgroup launch per V-cycle (default), 0 = per-op launches
+ * key 7: 1 = BC! as one closed-form launch (default), 0 = the reference's sequence of plane loops
  * key 4: rows per workgroup of the vectorised 7-point kernel: 0 = 4 rows / 256 threads (default), 1 = 8 rows / 512 */
 int wl_set_option(int key, int value);
 

@@ -7,13 +7,14 @@ import bench
 from waterlily_amd import _lib, sim as S
 size, key = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+vals = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (1, 0)
 L = _lib.lib()
 sim = bench.sphere((size,) * 3, np.float32)
 for _ in range(6):
     S.sim_step(sim, remeasure=False)
-res = {0: [], 1: []}
+res = {v: [] for v in vals}
 for r in range(reps):
-    for val in (1, 0):
+    for val in vals:
         _lib.check(L.wl_set_option(key, val))
         S.sim_step(sim, remeasure=False); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -21,5 +22,5 @@ for r in range(reps):
             S.sim_step(sim, remeasure=False)
         torch.cuda.synchronize()
         res[val].append((time.perf_counter() - t0) / 5 * 1e3)
-for val in (1, 0):
+for val in vals:
     print(f"{size}^3 option[{key}]={val}: median {np.median(res[val]):.3f} ms/step  (all: {[round(x, 2) for x in res[val]]})  n={sim.pois.n[-2:]}")

@@ -239,7 +239,8 @@ template <class T, int D> static int mg_vcycle(wl_mg *m, int l) {
         WL_HIP(hipMemsetAsync(coarse.x, 0, (size_t)span(coarse.g) * sizeof(T), ctx().stream));
     }
     // levels <= 4096 cells: the rest of the recursion + smooth!(coarse) as ONE single-workgroup launch (wl_coarse.h)
-    bool tail = ctx().opt[6] && fused && !coarse.g.dist && coarse.g.interior_cells() <= CV_MAXCELLS && (m->nlev - (l + 1)) <= CV_MAXLEV;
+    const long tail_cells = ctx().opt[6] == 1 ? CV_MAXCELLS : ctx().opt[6];   // option 6: 0 off, 1 default, else threshold
+    bool tail = ctx().opt[6] && fused && !coarse.g.dist && coarse.g.interior_cells() <= tail_cells && (m->nlev - (l + 1)) <= CV_MAXLEV;
     if (tail) {
         CoarseArgs<T> ca;
         ca.nlev = m->nlev - (l + 1);

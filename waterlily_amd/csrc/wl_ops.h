@@ -35,8 +35,10 @@ inline long span(const G &g) { return g.D == 3 ? (long)g.n[2] * g.s[2] : (long)g
 // ------------------------------------------------------------------------------------------ util.jl
 // BC!(a,A,saveexit,perdir)  src/util.jl:192-210 -- same sequence of plane loops as the reference, because
 // later planes read ghost values written by earlier ones (edges/corners).
+template <class T, int D> int op_bc_vec_fused(const G &g, T *a, const double *A, int saveexit, int permask);
 template <class T, int D>
 int op_bc_vec(const G &g, T *a, const double *A, int saveexit, int permask) {
+    if (ctx().opt[7]) return op_bc_vec_fused<T, D>(g, a, A, saveexit, permask);   // one launch (closed form), see below
     for (int c = 0; c < D; ++c)
         for (int j = 0; j < D; ++j) {
             T *ac = a + (long)c * g.sc;
@@ -67,6 +69,75 @@ int op_bc_vec(const G &g, T *a, const double *A, int saveexit, int permask) {
             }
         }
     return 0;
+}
+
+// BC!(a,A,saveexit,perdir) in ONE launch.  The reference applies its plane loops in the order (component i, direction j)
+// and later loops read ghost values written by earlier ones; the value a cell ends up with can be evaluated directly by
+// walking the passes of its component BACKWARDS: periodic j -> continue at the wrapped source index, tangential j ->
+// continue at the clamped source index, normal j -> the Dirichlet value A[i] (planes 1,2,N; N skipped when saving the
+// exit).  The walk ends on a cell no pass writes, so every thread reads only never-written cells: no ordering hazard.
+template <class T, int D>
+__global__ __launch_bounds__(256) void k_bc_vec_all(G g, T *a, T A0, T A1, T A2, int saveexit, int permask, long nthreads) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nthreads) return;
+    // thread -> (direction d, plane p in {0,1,n-1}, position in the plane, component c)
+    const int ng[3] = {g.n[0], g.n[1], D > 2 ? g.nzg : 1};
+    long rem = t;
+    int d = 0;
+    long per[3];
+    for (int q = 0; q < D; ++q) {
+        long cells = 3;
+        for (int e = 0; e < D; ++e) if (e != q) cells *= (e == 2 ? (long)(g.zhi - g.zlo + 1) : (long)g.n[e]);
+        per[q] = cells * D;
+    }
+    while (d < D - 1 && rem >= per[d]) { rem -= per[d]; ++d; }
+    if (rem >= per[d]) return;
+    const int c = (int)(rem % D);
+    rem /= D;
+    const int pl = (int)(rem % 3);
+    rem /= 3;
+    int idx[3] = {0, 0, 0};   // GLOBAL indices
+    for (int e = 0; e < D; ++e) {
+        if (e == d) { idx[e] = pl == 0 ? 0 : (pl == 1 ? 1 : ng[e] - 1); continue; }
+        const int ext = (e == 2) ? (g.zhi - g.zlo + 1) : g.n[e];
+        idx[e] = (int)(rem % ext) + (e == 2 ? g.zlo + g.kz0 : 0);
+        rem /= ext;
+    }
+    if (D > 2 && d == 2) {   // z planes: only the rank that owns them
+        const int kl = idx[2] - g.kz0;
+        if (kl < g.zlo || kl > g.zhi) return;
+    }
+    const long dst = g.at(idx[0], idx[1], D > 2 ? idx[2] - g.kz0 : 0) + (long)c * g.sc;
+    const T Ac = c == 0 ? A0 : (c == 1 ? A1 : A2);
+    bool dirichlet = false;
+    for (int j = D - 1; j >= 0; --j) {
+        const int n = ng[j];
+        if ((permask >> j) & 1) {
+            if (idx[j] == 0) idx[j] = n - 2;
+            else if (idx[j] == n - 1) idx[j] = 1;
+        } else if (j == c) {
+            if (idx[j] <= 1 || (idx[j] == n - 1 && (!saveexit || c > 0))) { dirichlet = true; break; }
+        } else {
+            if (idx[j] == 0) idx[j] = 1;
+            else if (idx[j] == n - 1) idx[j] = n - 2;
+        }
+    }
+    a[dst] = dirichlet ? Ac : a[g.at(idx[0], idx[1], D > 2 ? idx[2] - g.kz0 : 0) + (long)c * g.sc];
+}
+template <class T, int D>
+int op_bc_vec_fused(const G &g, T *a, const double *A, int saveexit, int permask) {
+    if (D > 2 && ((permask >> 2) & 1) && g.dist)
+        return fail(WL_E_ARG, "periodic z is not supported on a z-slab decomposition", __FILE__, __LINE__);
+    long total = 0;
+    for (int q = 0; q < D; ++q) {
+        long cells = 3;
+        for (int e = 0; e < D; ++e) if (e != q) cells *= (e == 2 ? (long)(g.zhi - g.zlo + 1) : (long)g.n[e]);
+        total += cells * D;
+    }
+    Prof p(WL_K_BC, total);
+    hipLaunchKernelGGL((k_bc_vec_all<T, D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, g, a, (T)A[0],
+                       (T)A[1], (T)(D > 2 ? A[2] : 0.0), saveexit, permask, total);
+    return (int)hipGetLastError();
 }
 
 // perBC!(a,perdir)  src/util.jl:227-231
