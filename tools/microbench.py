@@ -55,8 +55,6 @@ ab("pcg mult+dot (6T)", "pcg_mult_dot", 0, lambda: S.pcg(ml), 6)
 ab("increment (9T)", "increment", 0, lambda: S.increment(ml), 9)
 ab("residual (8T)", "residual", 0, lambda: S.residual(ml), 8)
 ab("V-cycle smoother (9T)", "smooth", 1, lambda: S.Vcycle(ml), 9)
-ab("pcg update (8T)", "pcg_update", 5, lambda: S.pcg(ml), 23 / 3)
-ab("pcg direction (3T)", "pcg_direction", 5, lambda: S.pcg(ml), 3)
 print("-- option[4]: 1 = 8 rows / 512 threads per workgroup, 0 = 4 rows / 256 threads")
 ab("pcg mult+dot (6T)", "pcg_mult_dot", 4, lambda: S.pcg(ml), 6)
 ab("increment (9T)", "increment", 4, lambda: S.increment(ml), 9)

@@ -805,8 +805,12 @@ _Pragma("unroll")
 // device flag: once `active` drops, the remaining (already enqueued) kernels are no-ops, so no host sync.
 // Fusions: [mult + z.eps], [x,r update + z=r*iD + r.z], [direction]; identical per-cell arithmetic.
 // want_r2: the caller (solver!) needs L2(p) = r.r right after this call; it is accumulated by the last update kernel.
+// scratch (optional): a level-sized buffer laid out like p.eps; when given (and the vector kernels apply, no periodic
+// direction, level not decomposed) iterations 2..it use the FUSED direction+mult kernel: eps_new = beta*eps + r*iD is
+// evaluated on the fly at the 7 stencil points and written out of place (eps <-> scratch ping-pong), z = r*iD is never
+// stored: 15T instead of 16T per iteration and one launch fewer; per-cell arithmetic unchanged.
 template <class T, int D>
-int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st, bool want_r2 = false) {
+int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st, bool want_r2 = false, T *scratch = nullptr) {
     const LevelT<T> q = p;
     const Range R = r_inside(p.g);
     const T eps10 = (T)10 * Lim<T>::eps;
@@ -814,8 +818,11 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     // streaming pcg kernels in 16-B vector form where the layout allows (wl_set_option(5,0) = scalar range kernels)
     bool vec = false;
     if constexpr (D == 3)
-        vec = ctx().opt[5] && stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.z, p.r) && stencil7_ok<T>(p.g, p.x, p.iD);
+        vec = ctx().opt[5] != 0 && stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.z, p.r) && stencil7_ok<T>(p.g, p.x, p.iD);
     using VA = VecA<T>;
+    const bool fusedir = vec && scratch && permask == 0 && !p.g.dist && ctx().opt[5] == 1 && ctx().opt[0] && stencil7_ok<T>(p.g, scratch, p.L) &&
+                         (long)((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 7) / 4) + 8 <= WL_MAXB;
+    T *ecur = p.eps, *eoth = scratch;   // (fusedir) buffer holding the current / next search direction
     // :125-127
     int rv0 = -1;
     if (vec) {
@@ -850,12 +857,27 @@ _Pragma("unroll")
         if constexpr (D == 3) {
             if (stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.z, p.L)) {
                 using VA = VecA<T>;
-                rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g, SrcArray<T>{p.eps}, p.L, [=] __device__(long o, const VA &ae, const VA &ec, double *acc) {
+                if (fusedir && n > 1) {
+                    // :140 of the previous iteration + :130-131: eps_new = beta*eps + r*iD (out of place), z = A eps_new
+                    T *eo = eoth;
+                    rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g, SrcDirection<T>{ecur, p.r, p.iD, &st->beta}, p.L,
+                        [=] __device__(long o, const VA &ae, const VA &ec, double *acc) {
+                            if (!st->active) return;
+                            ec.store(eo + o);
+                            ae.store(q.z + o);
+_Pragma("unroll")
+                            for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];
+                        }, partials, &np);
+                    if (rcv == 0) { T *tmp = ecur; ecur = eoth; eoth = tmp; }
+                } else {
+                const T *esrc = ecur;
+                rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g, SrcArray<T>{esrc}, p.L, [=] __device__(long o, const VA &ae, const VA &ec, double *acc) {
                     if (!st->active) return;
                     ae.store(q.z + o);
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];
                 }, partials, &np);
+                }
                 if (rcv > 0) return rcv;
             }
         }
@@ -882,7 +904,7 @@ _Pragma("unroll")
                 if (!st->active) return;
                 const T alpha = (T)st->alpha;
                 VA xv = VA::load(q.x + o), rr = VA::load(q.r + o);
-                const VA ev = VA::load(q.eps + o), zv = VA::load(q.z + o);
+                const VA ev = VA::load(ecur + o), zv = VA::load(q.z + o);
 _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) { xv.v[v] += alpha * ev.v[v]; rr.v[v] = rr.v[v] - alpha * zv.v[v]; }
                 xv.store(q.x + o);
@@ -892,7 +914,7 @@ _Pragma("unroll")
                     VA zn;
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) { zn.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zn.v[v]; }
-                    zn.store(q.z + o);
+                    if (!fusedir) zn.store(q.z + o);   // fused direction+mult recomputes r*iD: z' is never stored
                 } else if (want_r2) {
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) acc[0] += (double)rr.v[v] * (double)rr.v[v];
@@ -931,6 +953,7 @@ _Pragma("unroll")
         })));
         if (last) break;
         // :140
+        if (fusedir) continue;   // folded into the next iteration's mult kernel
         int rvd = -1;
         if (vec) {
             rvd = launch_rowvec<T, 0>(WL_K_PCG_DIR, p.g, [=] __device__(long o, int, int, double *) {

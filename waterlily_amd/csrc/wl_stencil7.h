@@ -58,6 +58,19 @@ template <class T> struct SrcJacobi {         // e = r*iD evaluated on the fly (
     }
     __device__ __forceinline__ T scal(long o, int, int, int) const { return r[o] * iD[o]; }
 };
+template <class T> struct SrcDirection {      // e = beta*eps + r*iD : pcg!'s new search direction on the fly (Poisson.jl:136,140)
+    const T *e, *r, *iD;
+    const double *beta;                        // device scalar, already rounded to T
+    __device__ __forceinline__ VecA<T> vec(long o, int, int, int) const {
+        const T b = (T)*beta;
+        const VecA<T> ev = VecA<T>::load(e + o), rv = VecA<T>::load(r + o), dv = VecA<T>::load(iD + o);
+        VecA<T> c;
+#pragma unroll
+        for (int v = 0; v < VecA<T>::V; ++v) c.v[v] = b * ev.v[v] + rv.v[v] * dv.v[v];
+        return c;
+    }
+    __device__ __forceinline__ T scal(long o, int, int, int) const { return (T)*beta * e[o] + r[o] * iD[o]; }
+};
 template <class T> struct SrcProlong {        // e[I] = coarse x[down(I)] inside, 0 on ghosts (MultiLevelPoisson.jl:2,34)
     const T *cx;
     G C;            // coarse grid
