@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 2
+#define WL_ABI_VERSION 3
 
 typedef enum wl_dtype { WL_F32 = 0, WL_F64 = 1 } wl_dtype;
 
@@ -48,6 +48,9 @@ typedef struct wl_grid {
      * own_lo, own_hi : LOCAL plane range this rank owns (writes); planes outside are halo copies of a
      *        neighbour's owned planes (filled by wl_halo_exchange) or unused padding. */
     int32_t nzg, kz0, own_lo, own_hi;
+    /* zring != 0: z is periodic ACROSS the slabs -- the ranks form a ring, the two z ghost planes are owned by nobody
+     * and are filled, like every halo plane, by the neighbour exchange (rank 0 <-> rank P-1 included). */
+    int32_t zring;
 } wl_grid;
 
 /* ------------------------------------------------------------------ runtime */
@@ -75,7 +78,7 @@ int wl_comm_init_rccl(const void *id128, int rank, int nranks);
  * allreduce: in-place on n doubles, op 0 = sum, 1 = max.  allgather: every rank contributes `bytes` at
  * offset rank*bytes of `buf`. */
 typedef int (*wl_host_sendrecv_fn)(void *user, const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi,
-                                   int64_t bytes);
+                                   int64_t bytes, int peer_lo, int peer_hi);
 typedef int (*wl_host_allreduce_fn)(void *user, double *vals, int n, int op);
 typedef int (*wl_host_allgather_fn)(void *user, void *buf, int64_t bytes);
 int wl_comm_init_host(int rank, int nranks, wl_host_sendrecv_fn sr, wl_host_allreduce_fn ar, wl_host_allgather_fn ag,

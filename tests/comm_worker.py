@@ -28,11 +28,17 @@ def main():
     r_lo, r_hi = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     lo, hi = rank > 0, rank < size - 1
-    ok &= sr(None, p(s_lo) if lo else None, p(r_lo) if lo else None, p(s_hi) if hi else None, p(r_hi) if hi else None, nb) == 0
+    ok &= sr(None, p(s_lo) if lo else None, p(r_lo) if lo else None, p(s_hi) if hi else None, p(r_hi) if hi else None, nb,
+             rank - 1 if lo else -1, rank + 1 if hi else -1) == 0
     if lo:
         ok &= bool(np.all(r_lo == 100 + rank - 1))
     if hi:
         ok &= bool(np.all(r_hi == rank + 1))
+    # periodic ring with 2 ranks: both peers are the same rank; the prescribed op order must pair hi->lo and lo->hi
+    other = (rank + 1) % size
+    r_lo[:] = 0; r_hi[:] = 0
+    ok &= sr(None, p(s_lo), p(r_lo), p(s_hi), p(r_hi), nb, other, other) == 0
+    ok &= bool(np.all(r_lo == 100 + other)) and bool(np.all(r_hi == other))
     # in-place allgather
     buf = np.zeros(size * 8, np.uint8)
     buf[rank * 8:(rank + 1) * 8] = rank + 1

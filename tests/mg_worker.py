@@ -41,9 +41,17 @@ def main():
         body, L, nu = AutoBody(sdf), Rm, Rm / 1000
     else:
         body, L, nu = AutoBody(lambda x, t: norm2(x - c) - R), 2 * R, 2 * R / 3700
-    kw = dict(nu=nu, body=body, T=T, exitBC=("exit" in case))
+    perdir = ()
+    if "zper" in case:
+        perdir = (2,)
+    if "yzper" in case:
+        perdir = (1, 2)
+    if "yper" in case:
+        perdir = (1,)
+    g = (lambda i, t: 0.05 * t if i == 0 else 0.0) if "accel" in case else None
+    kw = dict(nu=nu, body=body, T=T, exitBC=("exit" in case), perdir=perdir, g=g)
     ref = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=None, **kw)
-    slab = wd.Slab(rank, size, dims[2])
+    slab = wd.Slab(rank, size, dims[2], ring=(2 in perdir))
     # "deep": keep every level a slab as long as the partition allows; default: replicate levels <= 2^21 cells
     sim = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=slab, replicate_cells=0 if "deep" in case else 1 << 21, **kw)
     out = {"rank": rank, "levels": [(tuple(l.layout.Ng), l.layout.slab is not None) for l in sim.pois.levels]}
@@ -58,6 +66,10 @@ def main():
     out["dt_ref"], out["dt_slab"] = ref.flow.dt, sim.flow.dt
     for k in ("u", "p", "f"):
         a, b = S.gather(getattr(sim.flow, k)), S.to_host(getattr(ref.flow, k))
+        if 2 in perdir and k == "f":
+            # f on the two z GHOST planes: the reference leaves partial flux sums there (conv_diff! never periodic-copies
+            # f), a ring of slabs has no such planes (gather() fills them by wrapping): compare the interior planes
+            a, b = a[:, :, 1:-1], b[:, :, 1:-1]
         out["d_" + k] = float(np.max(np.abs(a - b)) / max(1e-30, np.max(np.abs(b))))
     out["force_ref"] = S.pressure_force(ref).tolist()
     out["force_slab"] = S.pressure_force(sim).tolist()

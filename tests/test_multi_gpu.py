@@ -79,11 +79,14 @@ def check(out, T):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nproc,case", [(2, "sphere_deep_f32"), (4, "sphere_long_deep_f32"), (2, "donut_deep_f64"),
-                                        (2, "sphere_exit_deep_f32"), (2, "sphere_f32")])
+                                        (2, "sphere_exit_deep_f32"), (2, "sphere_f32"),
+                                        (2, "sphere_zper_deep_f32"), (4, "sphere_long_zper_deep_f64"),
+                                        (2, "sphere_yzper_accel_deep_f64"), (2, "sphere_yper_exit_accel_f32")])
 def test_slabs_match_undecomposed(nproc, case):
     out = run_workers("mg_worker.py", nproc, case)
     # "deep", 32^3 on 2 ranks: levels 32,16,8 (16,8,4 planes per rank) are slabs, 4^3 and 2^3 are replicated;
     # default: only the finest level is a slab (coarser ones hold <= 2^21 cells and are replicated)
+    # z-periodic cases ("zper") run on a RING of slabs (rank 0 <-> rank P-1 exchange)
     nslab = sum(1 for _, d in out["levels"] if d)
     assert (nslab >= 3 if "deep" in case else nslab == 1) and not out["levels"][-1][1]
     check(out, "f64" if case.endswith("f64") else "f32")

@@ -24,7 +24,8 @@ class WlError(RuntimeError):
 
 class Grid(C.Structure):
     _fields_ = [("D", C.c_int32), ("n", C.c_int32 * 3), ("s", C.c_int64 * 3), ("sc", C.c_int64),
-                ("nzg", C.c_int32), ("kz0", C.c_int32), ("own_lo", C.c_int32), ("own_hi", C.c_int32)]
+                ("nzg", C.c_int32), ("kz0", C.c_int32), ("own_lo", C.c_int32), ("own_hi", C.c_int32),
+                ("zring", C.c_int32)]
 
 
 class LevelDesc(C.Structure):
@@ -36,7 +37,7 @@ class FlowDesc(C.Structure):
         ("nu", C.c_double), ("exitBC", C.c_int32), ("perdir_mask", C.c_int32)]
 
 
-SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 
@@ -136,7 +137,7 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.wl_abi_version() != 2:
+    if L.wl_abi_version() != 3:
         raise WlError("libwlhip.so ABI version mismatch; rebuild it")
     _lib = L
     return L

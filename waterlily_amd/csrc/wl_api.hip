@@ -23,11 +23,15 @@ struct RcclComm : Comm {
     int allreduce(double *dev, int n, int op) override {
         return chk(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, nc, ctx().stream), "allreduce");
     }
-    int sendrecv(const void *slo, void *rlo, const void *shi, void *rhi, size_t bytes) override {
+    int sendrecv(const void *slo, void *rlo, const void *shi, void *rhi, size_t bytes, int plo, int phi) override {
         int rc = chk(ncclGroupStart(), "groupStart");
         if (rc) return rc;
-        if (slo) { ncclSend(slo, bytes, ncclChar, rank - 1, nc, ctx().stream); ncclRecv(rlo, bytes, ncclChar, rank - 1, nc, ctx().stream); }
-        if (shi) { ncclSend(shi, bytes, ncclChar, rank + 1, nc, ctx().stream); ncclRecv(rhi, bytes, ncclChar, rank + 1, nc, ctx().stream); }
+        // order: my upper planes go up and fill the lower halo of peer_hi, whose first receive from me is its recv_lo, ...
+        // (with a 2-rank ring both peers are the same rank: k-th send must meet the k-th receive of that peer)
+        if (shi) ncclSend(shi, bytes, ncclChar, phi, nc, ctx().stream);
+        if (rlo) ncclRecv(rlo, bytes, ncclChar, plo, nc, ctx().stream);
+        if (slo) ncclSend(slo, bytes, ncclChar, plo, nc, ctx().stream);
+        if (rhi) ncclRecv(rhi, bytes, ncclChar, phi, nc, ctx().stream);
         return chk(ncclGroupEnd(), "groupEnd(sendrecv)");
     }
     int allgather(void *buf, size_t bytes) override {
@@ -58,13 +62,13 @@ struct HostComm : Comm {
         WL_HIP(hipStreamSynchronize(ctx().stream));
         return 0;
     }
-    int sendrecv(const void *slo, void *rlo, const void *shi, void *rhi, size_t bytes) override {
+    int sendrecv(const void *slo, void *rlo, const void *shi, void *rhi, size_t bytes, int plo, int phi) override {
         WL_TRY(need(4 * bytes));
         char *hs_lo = pin, *hr_lo = pin + bytes, *hs_hi = pin + 2 * bytes, *hr_hi = pin + 3 * bytes;
         if (slo) WL_HIP(hipMemcpyAsync(hs_lo, slo, bytes, hipMemcpyDeviceToHost, ctx().stream));
         if (shi) WL_HIP(hipMemcpyAsync(hs_hi, shi, bytes, hipMemcpyDeviceToHost, ctx().stream));
         WL_HIP(hipStreamSynchronize(ctx().stream));
-        if (sr(user, slo ? hs_lo : nullptr, slo ? hr_lo : nullptr, shi ? hs_hi : nullptr, shi ? hr_hi : nullptr, (int64_t)bytes))
+        if (sr(user, slo ? hs_lo : nullptr, slo ? hr_lo : nullptr, shi ? hs_hi : nullptr, shi ? hr_hi : nullptr, (int64_t)bytes, plo, phi))
             return fail(WL_E_STATE, "host sendrecv callback failed", __FILE__, __LINE__);
         if (rlo) WL_HIP(hipMemcpyAsync(rlo, hr_lo, bytes, hipMemcpyHostToDevice, ctx().stream));
         if (rhi) WL_HIP(hipMemcpyAsync(rhi, hr_hi, bytes, hipMemcpyHostToDevice, ctx().stream));
@@ -135,6 +139,8 @@ int check_grid(const wl_grid *g) {
             return fail(WL_E_ARG, "grid.own_lo/own_hi outside the local planes", __FILE__, __LINE__);
         if (g->kz0 + g->own_lo < 0 || g->kz0 + g->own_hi > g->nzg - 1)
             return fail(WL_E_ARG, "owned planes outside the global array", __FILE__, __LINE__);
+        if (g->zring && (g->kz0 + g->own_lo < 1 || g->kz0 + g->own_hi > g->nzg - 2))
+            return fail(WL_E_ARG, "zring: the z ghost planes must not be owned", __FILE__, __LINE__);
     }
     return 0;
 }

@@ -31,7 +31,8 @@ struct Comm {
     int rank = 0, size = 1;
     virtual ~Comm() {}
     virtual int allreduce(double *dev, int n, int op) = 0;                       // op: 0 sum, 1 max; in place
-    virtual int sendrecv(const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi, size_t bytes) = 0;
+    virtual int sendrecv(const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi, size_t bytes, int peer_lo,
+                         int peer_hi) = 0;
     virtual int allgather(void *buf, size_t bytes_per_rank) = 0;                  // in place, rank r at r*bytes
     virtual int group_begin() { return 0; }   // several sendrecv calls issued as ONE batch (one latency, not one each)
     virtual int group_end() { return 0; }
@@ -86,6 +87,7 @@ struct G {  // device-side copy of wl_grid (+ derived values)
     int kz0;           // global z index of local plane 0
     int zlo, zhi;      // owned local planes (inclusive)
     bool dist;         // z-slab of a decomposed array
+    bool zring;        // z periodic across the slabs (ring of ranks): no z boundary anywhere
     __host__ __device__ int kg(int k) const { return k + kz0; }
     __host__ __device__ long at(int i, int j, int k) const { return (long)i + s[1] * (long)j + s[2] * (long)k; }
     long cells() const { return (long)n[0] * n[1] * n[2]; }
@@ -100,8 +102,8 @@ inline G mkG(const wl_grid *g) {
     o.D = g->D;
     for (int d = 0; d < 3; ++d) { o.n[d] = g->n[d]; o.s[d] = g->s[d]; }
     o.sc = g->sc;
-    if (g->D == 3 && g->nzg > 0) { o.nzg = g->nzg; o.kz0 = g->kz0; o.zlo = g->own_lo; o.zhi = g->own_hi; o.dist = true; }
-    else { o.nzg = g->n[2]; o.kz0 = 0; o.zlo = 0; o.zhi = g->n[2] - 1; o.dist = false; }
+    if (g->D == 3 && g->nzg > 0) { o.nzg = g->nzg; o.kz0 = g->kz0; o.zlo = g->own_lo; o.zhi = g->own_hi; o.dist = true; o.zring = g->zring != 0; }
+    else { o.nzg = g->n[2]; o.kz0 = 0; o.zlo = 0; o.zhi = g->n[2] - 1; o.dist = false; o.zring = false; }
     return o;
 }
 int check_grid(const wl_grid *g);
@@ -357,14 +359,15 @@ template <class T> inline int halo_exchange(const G &g, T *a, int ncomp, int dep
     Comm *cm = ctx().comm;
     if (!g.dist || !cm || cm->size == 1) return 0;
     const size_t bytes = (size_t)depth * (size_t)g.s[2] * sizeof(T);
-    const bool lo = cm->rank > 0, hi = cm->rank < cm->size - 1;
+    const bool lo = g.zring || cm->rank > 0, hi = g.zring || cm->rank < cm->size - 1;
+    const int plo = lo ? (cm->rank - 1 + cm->size) % cm->size : -1, phi = hi ? (cm->rank + 1) % cm->size : -1;
     int rc = cm->group_begin();
     if (rc) return rc;
     for (int c = 0; c < ncomp; ++c) {
         T *b = a + (long)c * g.sc;
         rc = cm->sendrecv(lo ? b + (long)g.zlo * g.s[2] : nullptr, lo ? b + (long)(g.zlo - depth) * g.s[2] : nullptr,
                           hi ? b + (long)(g.zhi - depth + 1) * g.s[2] : nullptr,
-                          hi ? b + (long)(g.zhi + 1) * g.s[2] : nullptr, bytes);
+                          hi ? b + (long)(g.zhi + 1) * g.s[2] : nullptr, bytes, plo, phi);
         if (rc) { (void)cm->group_end(); return rc; }
     }
     return cm->group_end();

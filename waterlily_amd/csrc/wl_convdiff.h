@@ -131,9 +131,10 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
         // ---- B. fluxes of plane k
         const int s1 = (k + 3) % 3, s0 = (k + 2) % 3;  // LDS slots of planes k and k-1
         const int kg = k + kz0;                 // plane number in the undecomposed array
-        const bool klow = kg >= 1;
+        const bool ring = g.zring;              // periodic ring of slabs: every z face is an interior face
+        const bool klow = ring || kg >= 1;
         const bool lowok = jlow && klow;
-        const bool zlb = (kg == 1), ztb = (kg == nzg - 1);
+        const bool zlb = !ring && (kg == 1), ztb = !ring && (kg == nzg - 1);
         T rr[3] = {0, 0, 0};
         double Fz[3];
 #pragma unroll
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
                     rr[c] = cd_sub<T>(rr[c], cd_flux<T>(ym1, x0, yp1, yp2, vfu, nu, false, ytb), ytb);
                 }
                 // ---- z lower face of the own cell (cells k <= n2-2 take part in z)
-                if (kg <= nzg - 2) rr[c] = cd_add<T>(rr[c], Fz[c], zlb);
+                if (ring || kg <= nzg - 2) rr[c] = cd_add<T>(rr[c], Fz[c], zlb);
             }
         }
         // ---- C. finish and store: the carried cell k-1 gets its upper z flux; cell k is stored now when it
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
             carry = false;
         }
         if (own) {
-            const bool needs_up = lowok && (kg <= nzg - 2);
+            const bool needs_up = lowok && (ring || kg <= nzg - 2);
             if (needs_up) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { part[c] = rr[c]; cu0[c] = e0[c]; cV[c] = eV[c]; }

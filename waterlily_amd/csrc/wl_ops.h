@@ -45,8 +45,10 @@ int op_bc_vec(const G &g, T *a, const double *A, int saveexit, int permask) {
             const long sj = g.s[j];
             const int N = (j == 2) ? g.nzg : g.n[j];   // plane numbers along z are global
             const G gg = g;
-            if (((permask >> j) & 1) && j == 2 && g.dist)
-                return fail(WL_E_ARG, "periodic z is not supported on a z-slab decomposition", __FILE__, __LINE__);
+            if (((permask >> j) & 1) && j == 2 && g.dist) {
+                if (g.zring) continue;   // ring of slabs: the halo exchange that follows BC! fills the z ghost planes
+                return fail(WL_E_ARG, "periodic z on a z-slab decomposition needs grid.zring", __FILE__, __LINE__);
+            }
             if ((permask >> j) & 1) {
                 const long off = (long)(N - 2) * sj;
                 WL_TRY(launch_range(WL_K_BC, r_slice(g, 0, j, 0), [=] __device__(int i, int jj, int k) {
@@ -103,9 +105,9 @@ __global__ __launch_bounds__(256) void k_bc_vec_all(G g, T *a, T A0, T A1, T A2,
         idx[e] = (int)(rem % ext) + (e == 2 ? g.zlo + g.kz0 : 0);
         rem /= ext;
     }
-    if (D > 2 && d == 2) {   // z planes: only the rank that owns them
+    if (D > 2 && d == 2) {   // z planes: only the rank that owns them (nobody on a periodic ring: halo exchange fills them)
         const int kl = idx[2] - g.kz0;
-        if (kl < g.zlo || kl > g.zhi) return;
+        if (g.zring || kl < g.zlo || kl > g.zhi) return;
     }
     const long dst = g.at(idx[0], idx[1], D > 2 ? idx[2] - g.kz0 : 0) + (long)c * g.sc;
     const T Ac = c == 0 ? A0 : (c == 1 ? A1 : A2);
@@ -126,8 +128,8 @@ __global__ __launch_bounds__(256) void k_bc_vec_all(G g, T *a, T A0, T A1, T A2,
 }
 template <class T, int D>
 int op_bc_vec_fused(const G &g, T *a, const double *A, int saveexit, int permask) {
-    if (D > 2 && ((permask >> 2) & 1) && g.dist)
-        return fail(WL_E_ARG, "periodic z is not supported on a z-slab decomposition", __FILE__, __LINE__);
+    if (D > 2 && ((permask >> 2) & 1) && g.dist && !g.zring)
+        return fail(WL_E_ARG, "periodic z on a z-slab decomposition needs grid.zring", __FILE__, __LINE__);
     long total = 0;
     for (int q = 0; q < D; ++q) {
         long cells = 3;
@@ -145,7 +147,10 @@ template <class T, int D>
 int op_bc_per(const G &g, T *a, int permask) {
     for (int j = 0; j < D; ++j)
         if ((permask >> j) & 1) {
-            if (j == 2 && g.dist) return fail(WL_E_ARG, "periodic z is not supported on a z-slab decomposition", __FILE__, __LINE__);
+            if (j == 2 && g.dist) {
+                if (g.zring) continue;   // the exchange below is the periodic copy
+                return fail(WL_E_ARG, "periodic z on a z-slab decomposition needs grid.zring", __FILE__, __LINE__);
+            }
             const long off = (long)(g.n[j] - 2) * g.s[j];
             const G gg = g;
             WL_TRY(launch_range(WL_K_BC, r_slice(g, 0, j, 0), [=] __device__(int i, int jj, int k) {
@@ -214,7 +219,7 @@ int op_conv_diff_range(const G &g, const Range &R, T *r, const T *u, double nu_,
         const int idx[3] = {i, j, gg.kg(k)};   // z index in global numbering
         bool lowok = true;
 _Pragma("unroll")
-        for (int d = 0; d < D; ++d) lowok = lowok && idx[d] >= 1;
+        for (int d = 0; d < D; ++d) lowok = lowok && (idx[d] >= 1 || (d == 2 && gg.zring));
 _Pragma("unroll")
         for (int c = 0; c < D; ++c) {
             const T *ui = u + (long)c * gg.sc;
@@ -224,14 +229,15 @@ _Pragma("unroll")
 _Pragma("unroll")
                 for (int jd = 0; jd < D; ++jd) {
                     const int Nj = (jd == 2) ? gg.nzg : gg.n[jd];
-                    if (idx[jd] > Nj - 2) continue;
+                    const bool ring = (jd == 2) && gg.zring;   // periodic ring of slabs: every z face is an interior face
+                    if (!ring && idx[jd] > Nj - 2) continue;
                     const T *uj = u + (long)jd * gg.sc;
                     const long sj = gg.s[jd];
-                    const bool per = (permask >> jd) & 1;
+                    const bool per = ((permask >> jd) & 1) && !ring;
                     {   // lower face of the cell: face index I
                         const double uf = phi<T>(uj, I, si);
                         const T nud = nu * (T)(ui[I] - ui[I - sj]);
-                        if (idx[jd] == 1) {
+                        if (!ring && idx[jd] == 1) {
                             if (!per) {
                                 rr = (T)((double)rr + (phiuL<T>(ui, I, sj, uf) - (double)nud));
                             } else {
@@ -245,7 +251,7 @@ _Pragma("unroll")
                     }
                     {   // upper face of the cell: face index I+sj
                         const long J = I + sj;
-                        if (idx[jd] == Nj - 2) {
+                        if (!ring && idx[jd] == Nj - 2) {
                             if (!per) {
                                 const double uf = phi<T>(uj, J, si);
                                 const T nud = nu * (T)(ui[J] - ui[J - sj]);
@@ -285,7 +291,7 @@ template <class T, int D, bool FUSE, bool COPY = false>
 int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T *u0, const T *V, double dt_,
                  const double *acc, bool has_acc, T *u0out = nullptr) {
     if constexpr (D == 3) {
-        if (ctx().opt[2] && permask == 0 && g.n[0] >= 5 && g.n[1] >= 5 && g.n[2] >= 5) {
+        if (ctx().opt[2] && (permask == 0 || (permask == 4 && g.zring)) && g.n[0] >= 5 && g.n[1] >= 5 && g.n[2] >= 5) {
             WL_TRY((launch_convdiff3<T, FUSE, COPY>(g, r, u, nu_, u0, u0out, V, dt_, acc, has_acc)));
             Range R0 = r_whole(g), R1 = r_whole(g);
             R0.hi[0] = 0;

@@ -25,6 +25,7 @@ class Slab:
     rank: int
     size: int
     nz: int                      # global interior planes of this level
+    ring: bool = False           # z periodic across the slabs: ranks form a ring, nobody owns the z ghost planes
 
     def __post_init__(self):
         if self.nz % self.size:
@@ -33,15 +34,15 @@ class Slab:
         self.n2l = self.nzl + 2 * HZ              # local planes incl. halo
         self.nzg = self.nz + 2                    # global planes incl. the ghost layer
         self.kz0 = self.rank * self.nzl + 1 - HZ  # global index of local plane 0
-        self.own_lo = HZ - (1 if self.rank == 0 else 0)                 # rank 0 owns the lower ghost plane
-        self.own_hi = HZ + self.nzl - 1 + (1 if self.rank == self.size - 1 else 0)
+        self.own_lo = HZ - (1 if (self.rank == 0 and not self.ring) else 0)     # rank 0 owns the lower ghost plane
+        self.own_hi = HZ + self.nzl - 1 + (1 if (self.rank == self.size - 1 and not self.ring) else 0)
 
     def coarser(self) -> Optional["Slab"]:
         """The slab of the next multigrid level, or None when that level must be replicated
         (children of a coarse cell must live on one rank, and a slab needs >= 2 planes)."""
         if self.nzl % 2 or self.nzl // 2 < 2:
             return None
-        return Slab(self.rank, self.size, self.nz // 2)
+        return Slab(self.rank, self.size, self.nz // 2, self.ring)
 
 
 _state = {"kind": None, "rank": 0, "size": 1, "keep": None}
@@ -75,13 +76,18 @@ def host_callbacks(group=None):
     def view(ptr, nbytes):
         return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,)))
 
-    def sendrecv(user, slo, rlo, shi, rhi, nbytes):
+    def sendrecv(user, slo, rlo, shi, rhi, nbytes, plo, phi):
         try:
+            # order prescribed by include/wlhip.h (pairs correctly when plo == phi, a 2-rank periodic ring)
             ops = []
-            if slo:
-                ops += [dist.P2POp(dist.isend, view(slo, nbytes), rank - 1, group), dist.P2POp(dist.irecv, view(rlo, nbytes), rank - 1, group)]
             if shi:
-                ops += [dist.P2POp(dist.isend, view(shi, nbytes), rank + 1, group), dist.P2POp(dist.irecv, view(rhi, nbytes), rank + 1, group)]
+                ops.append(dist.P2POp(dist.isend, view(shi, nbytes), phi, group))
+            if rlo:
+                ops.append(dist.P2POp(dist.irecv, view(rlo, nbytes), plo, group))
+            if slo:
+                ops.append(dist.P2POp(dist.isend, view(slo, nbytes), plo, group))
+            if rhi:
+                ops.append(dist.P2POp(dist.irecv, view(rhi, nbytes), phi, group))
             for w in (dist.batch_isend_irecv(ops) if ops else []):
                 w.wait()
             return 0

@@ -77,6 +77,7 @@ class Layout:
         g.sc = self.sc
         if self.slab is not None:
             g.nzg, g.kz0, g.own_lo, g.own_hi = self.slab.nzg, self.slab.kz0, self.slab.own_lo, self.slab.own_hi
+            g.zring = int(self.slab.ring)
         return g
 
     def alloc(self, ncomp: Sequence[int], device, fill: float = 0.0) -> torch.Tensor:
@@ -107,6 +108,7 @@ def _grid_of(a: torch.Tensor, D: int) -> Grid:
     sl = getattr(a, "_wl_slab", None)
     if sl is not None:
         g.nzg, g.kz0, g.own_lo, g.own_hi = sl.nzg, sl.kz0, sl.own_lo, sl.own_hi
+        g.zring = int(sl.ring)
     return g
 
 
@@ -248,7 +250,10 @@ def gather(a: torch.Tensor) -> np.ndarray:
         import torch.distributed as dist
         parts = [None] * sl.size
         dist.all_gather_object(parts, mine)
-    return np.asfortranarray(np.moveaxis(np.concatenate(parts, axis=0), 0, 2))
+    full = np.concatenate(parts, axis=0)
+    if sl.ring:   # nobody owns the two z ghost planes of a periodic ring: they are the wrapped interior planes
+        full = np.concatenate([full[-1:], full, full[:1]], axis=0)
+    return np.asfortranarray(np.moveaxis(full, 0, 2))
 
 
 def exitBC(u: torch.Tensor, u0: torch.Tensor, U, dt: float) -> None:
@@ -297,8 +302,10 @@ class Flow:
         Ng = tuple(int(n) + 2 for n in N)
         self.N = Ng                      # extents of the undecomposed arrays (the reference's size(p))
         self.slab = slab
-        if slab is not None and (D != 3 or 2 in tuple(perdir)):
-            raise ValueError("z-slab decomposition needs D == 3 and a non-periodic z direction")
+        if slab is not None and D != 3:
+            raise ValueError("z-slab decomposition needs D == 3")
+        if slab is not None and slab.ring != (2 in tuple(perdir)):
+            raise ValueError("Slab.ring must be set exactly when z (direction 2) is periodic")
         self.layout = Layout(Ng, T, padded, slab)
         self.U, self.g, self.nu = U, g, float(nu)
         self.perdir, self.exitBC = tuple(int(j) for j in perdir), bool(exitBC)
@@ -583,7 +590,7 @@ class Simulation:
         if slab == "auto":   # one z-slab per rank once a communicator exists (waterlily_amd.dist.init_*)
             from . import dist as _dist
             r, n = _dist.rank_size()
-            slab = _dist.Slab(r, n, int(dims[2])) if (n > 1 and len(dims) == 3) else None
+            slab = _dist.Slab(r, n, int(dims[2]), ring=(2 in tuple(perdir))) if (n > 1 and len(dims) == 3) else None
         self.slab = slab
         self.flow = Flow(dims, u_BC, ulam=ulam, dt=dt, nu=nu, g=g, T=T, perdir=perdir, exitBC=exitBC,
                          device=device, padded=padded, slab=slab)
