@@ -1,0 +1,207 @@
+# WaterLilyHIPNativeExt.jl -- reference-side binding of libwlhip.so (include/wlhip.h, ABI v3).
+#
+# NOT EXECUTED by this repository's tests: no Julia runtime exists in the build image or on the GPU box.  It is the
+# shim a WaterLily maintainer would add as a package extension (compare ext/WaterLilyAMDGPUExt.jl): a device array type
+# plus method overrides at function granularity, every one of them a plain `ccall`.  The Python host
+# (waterlily_amd/sim.py) binds exactly the same entry points and is what the parity tests exercise.
+#
+#   using WaterLily, WaterLilyHIPNativeExt
+#   sim = Simulation((512,512,512), (1,0,0), 128; ν=128/3700, body=AutoBody(...), T=Float32, mem=HIPArray)
+#   sim_step!(sim; remeasure=false)
+module WaterLilyHIPNativeExt
+
+using WaterLily
+import WaterLily: Flow, Poisson, MultiLevelPoisson, AbstractPoisson, AbstractBody, mom_step!, conv_diff!, BDIM!, project!,
+                  BC!, exitBC!, perBC!, scale_u!, CFL, set_diag!, mult!, residual!, increment!, Jacobi!, pcg!, L₂,
+                  solver!, restrict!, prolongate!, restrictL!, Vcycle!, update!, measure!, apply!, pressure_force,
+                  viscous_force, pressure_moment, BCTuple, nds, loc, inside, time
+using StaticArrays
+
+const lib = get(ENV, "WLHIP_LIB", "libwlhip.so")
+
+# ---------------------------------------------------------------------------------------------- plumbing
+struct WlGrid            # == wl_grid
+    D::Int32; n::NTuple{3,Int32}; s::NTuple{3,Int64}; sc::Int64
+    nzg::Int32; kz0::Int32; own_lo::Int32; own_hi::Int32; zring::Int32
+end
+struct WlLevel           # == wl_level_desc
+    g::WlGrid; L::Ptr{Cvoid}; D::Ptr{Cvoid}; iD::Ptr{Cvoid}; x::Ptr{Cvoid}; eps::Ptr{Cvoid}; r::Ptr{Cvoid}; z::Ptr{Cvoid}
+end
+struct WlFlow            # == wl_flow_desc
+    g::WlGrid; u::Ptr{Cvoid}; u0::Ptr{Cvoid}; f::Ptr{Cvoid}; p::Ptr{Cvoid}; sigma::Ptr{Cvoid}; V::Ptr{Cvoid}
+    mu0::Ptr{Cvoid}; mu1::Ptr{Cvoid}; nu::Cdouble; exitBC::Int32; perdir_mask::Int32
+end
+chk(rc) = rc == 0 ? nothing : (rc == 10002 ? throw(AssertionError("MultiLevelPoisson requires size=a2ⁿ, where n>2")) :
+                               error(unsafe_string(ccall((:wl_last_error, lib), Cstring, ()))))
+dtype(::Type{Float32}) = Cint(0)
+dtype(::Type{Float64}) = Cint(1)
+mask(perdir) = Cint(reduce(|, (1 << (j - 1) for j in perdir); init=0))        # 1-based tuple -> 0-based bit mask
+d3(A) = Cdouble[A..., 0, 0][1:3]
+
+# ---------------------------------------------------------------------------------------------- device array
+"""Dense column-major device array (the reference layout, src/Flow.jl:112-118) owning memory from `wl_malloc`."""
+mutable struct HIPArray{T,N} <: AbstractArray{T,N}
+    ptr::Ptr{T}
+    dims::NTuple{N,Int}
+    function HIPArray{T,N}(dims::NTuple{N,Int}) where {T,N}
+        p = Ref{Ptr{Cvoid}}()
+        chk(ccall((:wl_malloc, lib), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, max(1, prod(dims)) * sizeof(T)))
+        a = new{T,N}(Ptr{T}(p[]), dims)
+        finalizer(x -> ccall((:wl_free, lib), Cint, (Ptr{Cvoid},), x.ptr), a)
+    end
+end
+HIPArray(h::Array{T,N}) where {T,N} = copyto!(HIPArray{T,N}(size(h)), h)       # `zeros(T,Nd) |> mem` (Flow.jl:114-118)
+Base.size(a::HIPArray) = a.dims
+Base.similar(a::HIPArray{T}, ::Type{S}=T, dims::Dims=a.dims) where {T,S} = HIPArray{S,length(dims)}(dims)
+Base.copyto!(d::HIPArray{T}, h::Array{T}) where T =
+    (chk(ccall((:wl_h2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), d.ptr, h, sizeof(h))); d)
+Base.copyto!(h::Array{T}, d::HIPArray{T}) where T =
+    (chk(ccall((:wl_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), h, d.ptr, sizeof(h))); h)
+Base.Array(a::HIPArray{T,N}) where {T,N} = copyto!(Array{T,N}(undef, a.dims), a)
+Base.copy(a::HIPArray) = HIPArray(Array(a))
+Base.fill!(a::HIPArray{T}, v) where T = iszero(v) ?
+    (chk(ccall((:wl_memset0, lib), Cint, (Ptr{Cvoid}, Csize_t), a.ptr, sizeof(T) * length(a))); a) : copyto!(a, fill(T(v), size(a)))
+Base.getindex(a::HIPArray, I...) = Array(a)[I...]                               # tests only (GPUArrays.@allowscalar style)
+Base.sum(a::HIPArray) = sum(Array(a))
+Base.maximum(a::HIPArray) = maximum(Array(a))
+
+grid(a::HIPArray, D=ndims(a)) = (n = (size(a)[1:D]..., ntuple(_ -> 1, 3 - D)...);
+    WlGrid(D, Int32.(n), (1, n[1], n[1] * n[2]), prod(n), 0, 0, 0, 0, 0))
+
+# ---------------------------------------------------------------------------------------------- util.jl
+BC!(a::HIPArray{T}, A, saveexit=false, perdir=()) where T =                                  # src/util.jl:192-210
+    chk(ccall((:wl_bc_vec, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint),
+              dtype(T), grid(a, ndims(a) - 1), a.ptr, d3(A), saveexit, mask(perdir)))
+perBC!(a::HIPArray, ::Tuple{}) = nothing
+perBC!(a::HIPArray{T}, perdir, N=size(a)) where T =                                           # src/util.jl:227-231
+    chk(ccall((:wl_bc_per, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Cint), dtype(T), grid(a), a.ptr, mask(perdir)))
+exitBC!(u::HIPArray{T}, u⁰::HIPArray{T}, U, Δt) where T =                                      # src/util.jl:216-222
+    chk(ccall((:wl_exit_bc, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cdouble),
+              dtype(T), grid(u, ndims(u) - 1), u.ptr, u⁰.ptr, d3(U), Δt))
+function L₂(a::HIPArray{T}) where T                                                            # src/util.jl:68
+    o = Ref{Cdouble}()
+    chk(ccall((:wl_L2_inside, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ref{Cdouble}), dtype(T), grid(a), a.ptr, o)); o[]
+end
+function apply!(f, c::HIPArray)                                                                # src/util.jl:170-172
+    h = Array(c); apply!(f, h); copyto!(c, h)                                                  # user closure: host, then upload
+end
+
+# ---------------------------------------------------------------------------------------------- Flow.jl operators
+conv_diff!(r::HIPArray{T}, u::HIPArray{T}, Φ; ν=0.1, perdir=()) where T =                       # src/Flow.jl:36-60
+    chk(ccall((:wl_conv_diff, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint),
+              dtype(T), grid(u, ndims(u) - 1), r.ptr, u.ptr, ν, mask(perdir)))
+BDIM!(a::Flow{N,T,<:HIPArray}) where {N,T} =                                                    # src/Flow.jl:131-135
+    chk(ccall((:wl_bdim, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+              Ptr{Cvoid}, Cdouble), dtype(T), grid(a.p), a.u.ptr, a.u⁰.ptr, a.f.ptr, a.V.ptr, a.μ₀.ptr, a.μ₁.ptr, a.Δt[end]))
+scale_u!(a::Flow{N,T,<:HIPArray}, scale) where {N,T} =                                          # src/Flow.jl:170
+    chk(ccall((:wl_scale_u, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Cdouble), dtype(T), grid(a.p), a.u.ptr, scale))
+function CFL(a::Flow{N,T,<:HIPArray}; Δt_max=10) where {N,T}                                    # src/Flow.jl:172-175
+    o = Ref{Cdouble}()
+    chk(ccall((:wl_cfl, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ref{Cdouble}),
+              dtype(T), grid(a.p), a.σ.ptr, a.u.ptr, a.ν, o)); T(o[])
+end
+
+# ---------------------------------------------------------------------------------------------- handles
+const MG = IdDict{Any,Ptr{Cvoid}}()
+const FL = IdDict{Any,Ptr{Cvoid}}()
+level(l) = WlLevel(grid(l.x), l.L.ptr, l.D.ptr, l.iD.ptr, l.x.ptr, l.ϵ.ptr, l.r.ptr, l.z.ptr)
+function handle(p::AbstractPoisson{T,<:HIPArray}) where T                                       # Poisson.jl:31 / MultiLevelPoisson.jl:51
+    get!(MG, p) do
+        lv = p isa MultiLevelPoisson ? [level(l) for l in p.levels] : [level(p)]
+        h = Ref{Ptr{Cvoid}}()
+        chk(ccall((:wl_mg_create, lib), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Ptr{WlLevel}, Cint), h, dtype(T), length(lv), lv,
+                  mask(p.perdir)))
+        h[]
+    end
+end
+function handle(a::Flow{N,T,<:HIPArray}) where {N,T}
+    get!(FL, a) do
+        d = WlFlow(grid(a.p), a.u.ptr, a.u⁰.ptr, a.f.ptr, a.p.ptr, a.σ.ptr, a.V.ptr, a.μ₀.ptr, a.μ₁.ptr, a.ν, a.exitBC, mask(a.perdir))
+        h = Ref{Ptr{Cvoid}}()
+        chk(ccall((:wl_flow_create, lib), Cint, (Ref{Ptr{Cvoid}}, Cint, Ref{WlFlow}), h, dtype(T), d)); h[]
+    end
+end
+lvl(p, l) = p isa MultiLevelPoisson ? l - 1 : 0
+
+# ---------------------------------------------------------------------------------------------- Poisson.jl / MultiLevelPoisson.jl
+set_diag!(D::HIPArray{T}, iD::HIPArray{T}, L::HIPArray{T}) where T =                            # src/Poisson.jl:42-45
+    chk(ccall((:wl_set_diag, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), dtype(T), grid(D), D.ptr, iD.ptr, L.ptr))
+update!(p::AbstractPoisson{T,<:HIPArray}) where T = chk(ccall((:wl_mg_update, lib), Cint, (Ptr{Cvoid},), handle(p)))
+mult!(p::AbstractPoisson{T,<:HIPArray}, x::HIPArray) where T =                                  # src/Poisson.jl:62-68
+    (chk(ccall((:wl_mg_mult, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), handle(p), 0, x.ptr)); p.z)
+residual!(p::Poisson{T,<:HIPArray}) where T = chk(ccall((:wl_mg_residual, lib), Cint, (Ptr{Cvoid}, Cint), handle(p), 0))
+increment!(p::Poisson{T,<:HIPArray}) where T = chk(ccall((:wl_mg_increment, lib), Cint, (Ptr{Cvoid}, Cint), handle(p), 0))
+Jacobi!(p::Poisson{T,<:HIPArray}; it=1) where T = chk(ccall((:wl_mg_jacobi, lib), Cint, (Ptr{Cvoid}, Cint, Cint), handle(p), 0, it))
+pcg!(p::Poisson{T,<:HIPArray}; it=6) where T =
+    chk(ccall((:wl_mg_pcg, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}), handle(p), 0, it, C_NULL))
+function L₂(p::Poisson{T,<:HIPArray}) where T                                                   # src/Poisson.jl:146
+    o = Ref{Cdouble}(); chk(ccall((:wl_mg_L2, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), handle(p), 0, o)); T(o[])
+end
+Vcycle!(ml::MultiLevelPoisson{T,<:HIPArray}; l=1) where T = chk(ccall((:wl_mg_vcycle, lib), Cint, (Ptr{Cvoid}, Cint), handle(ml), l - 1))
+restrict!(a::HIPArray{T}, b::HIPArray{T}) where T =                                             # MultiLevelPoisson.jl:33
+    chk(ccall((:wl_restrict, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ref{WlGrid}, Ptr{Cvoid}), dtype(T), grid(a), a.ptr, grid(b), b.ptr))
+prolongate!(a::HIPArray{T}, b::HIPArray{T}) where T =                                           # MultiLevelPoisson.jl:34
+    chk(ccall((:wl_prolongate, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ref{WlGrid}, Ptr{Cvoid}), dtype(T), grid(a), a.ptr, grid(b), b.ptr))
+restrictL!(a::HIPArray{T}, b::HIPArray{T}; perdir=()) where T =                                 # MultiLevelPoisson.jl:26-32
+    chk(ccall((:wl_restrictL, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ref{WlGrid}, Ptr{Cvoid}, Cint),
+              dtype(T), grid(a, ndims(a) - 1), a.ptr, grid(b, ndims(b) - 1), b.ptr, mask(perdir)))
+function solver!(p::AbstractPoisson{T,<:HIPArray}; tol=1e-4, itmx=(p isa MultiLevelPoisson ? 32 : 1e3)) where T
+    n = Ref{Cint}()                                                                             # MultiLevelPoisson.jl:87 / Poisson.jl:162
+    chk(ccall((:wl_mg_solve, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint, Ref{Cint}), handle(p), tol, Int(itmx), n))
+    push!(p.n, n[])
+end
+
+# ---------------------------------------------------------------------------------------------- Flow.jl drivers
+function accel(a::Flow{N}, dt) where N                                                          # accelerate! (src/Flow.jl:68-73)
+    (a.g === nothing && a.U isa Tuple) && return C_NULL
+    t = sum(dt)
+    g(i) = (a.g === nothing ? 0.0 : a.g(i, t)) + (a.U isa Function ? WaterLily.ForwardDiff.derivative(τ -> a.U(i, τ), t) : 0.0)
+    d3(ntuple(g, N))
+end
+function project!(a::Flow{N,T,<:HIPArray}, b::AbstractPoisson, w=1) where {N,T}                 # src/Flow.jl:137-145
+    n = Ref{Cint}()
+    chk(ccall((:wl_project, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ref{Cint}), handle(a), handle(b), a.Δt[end], w, n))
+    push!(b.n, n[])
+end
+function mom_step!(a::Flow{N,T,<:HIPArray}, b::AbstractPoisson) where {N,T}                     # src/Flow.jl:153-169
+    U = d3(BCTuple(a.U, a.Δt, N))
+    gp, gc = accel(a, @view(a.Δt[1:end-1])), accel(a, a.Δt)
+    dt, n2 = Ref{Cdouble}(), zeros(Cint, 2)
+    chk(ccall((:wl_mom_step, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+              Ref{Cdouble}, Ptr{Cint}), handle(a), handle(b), a.Δt[end], U, gp, gc, dt, n2))
+    append!(b.n, n2); push!(a.Δt, T(dt[]))
+end
+
+# ---------------------------------------------------------------------------------------------- Body.jl / Metrics.jl
+function measure!(a::Flow{N,T,<:HIPArray}, body::AbstractBody; t=zero(T), ϵ=1) where {N,T}     # src/Body.jl:31-53
+    h = Flow(size(a.p) .- 2, a.U; f=Array, T, perdir=a.perdir, exitBC=a.exitBC)                 # host scratch with the same shape
+    measure!(h, body; t, ϵ)                                                                      # user closures + ForwardDiff on the host
+    copyto!(a.μ₀, h.μ₀); copyto!(a.μ₁, h.μ₁); copyto!(a.V, h.V); copyto!(a.σ, h.σ)
+    chk(ccall((:wl_flow_update, lib), Cint, (Ptr{Cvoid},), handle(a)))                          # rebuild the body-free row flags
+end
+function band(p::HIPArray, body, t)                                                             # Metrics.jl:84-87 on the |d|<=1 band
+    T = promote_type(Float64, eltype(p)); idx = Int64[]; v = Float64[]
+    for I ∈ inside(p)
+        n = nds(body, loc(0, I, T), t)
+        any(!iszero, n) && (push!(idx, LinearIndices(size(p))[I] - 1); append!(v, n))
+    end
+    HIPArray(idx), HIPArray(v)
+end
+function pressure_force(p::HIPArray{T}, df, body, t=0, ::Type=Float64) where T                  # src/Metrics.jl:94-100
+    idx, v = band(p, body, t); o = zeros(Cdouble, 3)
+    chk(ccall((:wl_pforce, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{Cdouble}, Int64, Ptr{Cdouble}),
+              dtype(T), grid(p), p.ptr, idx.ptr, v.ptr, length(idx), o)); o[1:ndims(p)]
+end
+function viscous_force(u::HIPArray{T}, ν, df, body, t=0, ::Type=Float64) where T                # src/Metrics.jl:109-113
+    p1 = HIPArray{T,ndims(u)-1}(size(u)[1:end-1]); idx, v = band(p1, body, t); o = zeros(Cdouble, 3)
+    chk(ccall((:wl_vforce, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{Cdouble}, Int64, Cdouble, Ptr{Cdouble}),
+              dtype(T), grid(u, ndims(u) - 1), u.ptr, idx.ptr, v.ptr, length(idx), ν, o)); o[1:ndims(u)-1]
+end
+function pressure_moment(x₀, p::HIPArray{T}, df, body, t=0, ::Type=Float64) where T             # src/Metrics.jl:130-134
+    idx, v = band(p, body, t); o = zeros(Cdouble, 3)
+    chk(ccall((:wl_pmoment, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Ptr{Cdouble}),
+              dtype(T), grid(p), p.ptr, idx.ptr, v.ptr, length(idx), d3(x₀), o)); o[1:ndims(p)]
+end
+
+export HIPArray
+end # module
