@@ -206,6 +206,16 @@ int wl_vforce(wl_dtype t, const wl_grid *g, const void *u, const int64_t *idx_de
 int wl_pmoment(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx_dev, const double *nds_dev, int64_t nband,
                const double x0[3], double out[3]);
 
+/* Field metrics over inside(out) (src/Metrics.jl:14-77), `@inside out[I] = metric(I,u)`:
+ *   WL_M_KE      ke(I,u,U)            0.125*sum_i (u[I,i]+u[I+d_i,i]-2U_i)^2          (par = U)
+ *   WL_M_CURL    curl(i,I,u)          component i=ipar of curl u at the cell EDGE      (D==2: i=3 -> ipar=2)
+ *   WL_M_OMAG    omega_mag(I,u)       |curl u| at the cell centre                      (D==3)
+ *   WL_M_OTHETA  omega_theta(I,z,c,u) omega . theta, theta = z x (loc(0,I)-c)          (par = z[3], par2 = c[3]; D==3)
+ *   WL_M_LAMBDA2 lambda2(I,u)         middle eigenvalue of S^2+Omega^2                 (D==3) */
+enum { WL_M_KE = 0, WL_M_CURL = 1, WL_M_OMAG = 2, WL_M_OTHETA = 3, WL_M_LAMBDA2 = 4 };
+int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, int ipar, const double par[3],
+              const double par2[3]);
+
 /* ------------------------------------------------------------------ tuning switches (A/B measurements)
  * key 0: 1 = use the 16-B-vectorised z-marching 7-point kernel where it applies (default), 0 = generic range kernel
  * key 1: 1 = fused V-cycle smoothers (default), 0 = the reference's two-pass Jacobi!/increment!/prolongate!

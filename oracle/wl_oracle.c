@@ -34,6 +34,28 @@ typedef struct wlo_grid {
 static int wlo_interior_reductions = 0;
 void wlo_set_interior_reductions(int on) { wlo_interior_reductions = on; }
 
+/* middle eigenvalue of a symmetric 3x3 matrix (closed form): lambda2 = eigvals(Hermitian(S^2+Omega^2))[2] */
+static double wlo_sym3_mid_eig(double a00, double a01, double a02, double a11, double a12, double a22) {
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    const double q = (a00 + a11 + a22) / 3.0;
+    if (p1 == 0.0) {
+        double x = a00, y = a11, z = a22, t;
+        if (x > y) { t = x; x = y; y = t; }
+        if (y > z) { t = y; y = z; z = t; }
+        if (x > y) { t = x; x = y; y = t; }
+        return y;
+    }
+    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+    const double p = sqrt(p2 / 6.0);
+    const double c00 = b00 / p, c11 = b11 / p, c22 = b22 / p, c01 = a01 / p, c02 = a02 / p, c12 = a12 / p;
+    double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    const double phi = acos(r) / 3.0;
+    const double e1 = q + 2.0 * p * cos(phi), e3 = q + 2.0 * p * cos(phi + 2.0943951023931953);
+    return 3.0 * q - e1 - e3;
+}
+
 #define T float
 #define SUF(x) x##_f32
 #define WLO_EPS FLT_EPSILON

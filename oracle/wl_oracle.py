@@ -116,6 +116,7 @@ def _declare(L: C.CDLL) -> None:
         f("wlo_flow_create", vp, gp, vp, vp, vp, vp, vp, vp, vp, vp, d, i, i)
         f("wlo_flow_destroy", None, vp)
         f("wlo_pforce", None, vp, vp, gp, C.POINTER(C.c_long), dp, lg, dp)
+        f("wlo_metric", None, i, vp, vp, gp, i, dp, dp)
         f("wlo_vforce", None, vp, vp, gp, C.POINTER(C.c_long), dp, lg, d, dp)
         f("wlo_pmoment", None, vp, vp, gp, C.POINTER(C.c_long), dp, lg, dp, dp)
         for nm in ("quick", "vanleer"):
@@ -483,6 +484,16 @@ def pressure_force_band(p: np.ndarray, df: np.ndarray, idx: np.ndarray, nds: np.
     _fn("wlo_pforce", p.dtype)(_p(p), _p(df), C.byref(Grid.of(p.shape)), idx.ctypes.data_as(C.POINTER(C.c_long)),
                                nds.ctypes.data_as(C.POINTER(C.c_double)), len(idx), out)
     return np.array(out[:D])
+
+
+_METRIC = {"ke": 0, "curl": 1, "omega_mag": 2, "omega_theta": 3, "lambda2": 4}
+
+
+def metric(out: np.ndarray, kind: str, u: np.ndarray, i: int = 0, par=None, par2=None) -> np.ndarray:
+    """Metrics.jl:14-77 over inside(out)"""
+    _fn("wlo_metric", u.dtype)(_METRIC[kind], _p(out), _p(u), C.byref(Grid.of(out.shape)), int(i),
+                               None if par is None else _d3(par), None if par2 is None else _d3(par2))
+    return out
 
 
 def viscous_force_band(u: np.ndarray, nu: float, df: np.ndarray, idx: np.ndarray, nds: np.ndarray) -> np.ndarray:

@@ -828,6 +828,57 @@ void SUF(wlo_pmoment)(const T *p, T *df, const wlo_grid *g, const long *idx, con
     }
 }
 
+/* Metrics.jl:14-77 field metrics over inside(out): kind 0 ke(I,u,U), 1 curl(i,I,u), 2 omega_mag, 3 omega_theta(I,z,c,u),
+ * 4 lambda2 (see include/wlhip.h wl_metric for the parameter conventions). */
+void SUF(wlo_metric)(int kind, T *out, const T *u, const wlo_grid *g, int ipar, const double *par, const double *par2) {
+    const int D = g->D;
+    const long nc = g->ncell;
+    const long *S = g->s;
+    WLO_LOOP(SUF(inside)(g), {
+        T res = 0;
+        if (kind == 0) {
+            double s = 0;
+            for (int c = 0; c < D; ++c) {
+                const double v = (double)(T)(u[I + c * nc] + u[I + S[c] + c * nc]) - 2.0 * (par ? par[c] : 0.0);
+                s += v * v;
+            }
+            res = (T)(0.125 * s);
+        } else if (kind == 1) {
+            const int a = (ipar + 1) % 3, b = (ipar + 2) % 3;
+            res = (u[I + b * nc] - u[I - S[a] + b * nc]) - (u[I + a * nc] - u[I - S[b] + a * nc]);
+        } else if (D == 3) {
+            T w[3];
+            for (int c = 0; c < 3; ++c) {
+                const int a = (c + 1) % 3, b = (c + 2) % 3;
+                w[c] = SUF(dudx)(u, g, I, b, a) - SUF(dudx)(u, g, I, a, b);
+            }
+            if (kind == 2) {
+                res = (T)sqrt((double)(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]));
+            } else if (kind == 3) {
+                const double x[3] = {(double)i - 0.5 - par2[0], (double)j - 0.5 - par2[1], (double)k - 0.5 - par2[2]};
+                const double th[3] = {par[1] * x[2] - par[2] * x[1], par[2] * x[0] - par[0] * x[2], par[0] * x[1] - par[1] * x[0]};
+                const double n = sqrt(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+                res = n <= 2.220446049250313e-16 * n ? (T)0 : (T)((th[0] * (double)w[0] + th[1] * (double)w[1] + th[2] * (double)w[2]) / n);
+            } else {
+                double J[3][3], M[3][3];
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) J[a][b] = (double)SUF(dudx)(u, g, I, a, b);
+                for (int a = 0; a < 3; ++a)
+                    for (int b = a; b < 3; ++b) {
+                        double m = 0;
+                        for (int c = 0; c < 3; ++c) {
+                            const double sa = 0.5 * (J[a][c] + J[c][a]), sb = 0.5 * (J[c][b] + J[b][c]);
+                            const double oa = 0.5 * (J[a][c] - J[c][a]), ob = 0.5 * (J[c][b] - J[b][c]);
+                            m += sa * sb + oa * ob;
+                        }
+                        M[a][b] = m;
+                    }
+                res = (T)wlo_sym3_mid_eig(M[0][0], M[0][1], M[0][2], M[1][1], M[1][2], M[2][2]);
+            }
+        }
+        out[I] = res;
+    });
+}
+
 /* known-answer helpers exported for tests/test_oracle_pins.py */
 double SUF(wlo_t_quick)(double u, double c, double d) { return (double)SUF(quick)((T)u, (T)c, (T)d); }
 double SUF(wlo_t_vanleer)(double u, double c, double d) { return (double)SUF(vanleer)((T)u, (T)c, (T)d); }

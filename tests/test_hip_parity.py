@@ -529,3 +529,23 @@ def test_vtk_write_restart_roundtrip(D, tmp_path):
     assert torch.equal(sim.flow.mu0, restart.flow.mu0)
     assert sim.flow.dt[-1] == restart.flow.dt[-1]
     assert abs(S.sim_time(sim) - S.sim_time(restart)) < 1e-3
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_field_metrics_parity(T):
+    """Metrics.jl:14-77 field metrics: the reference's analytic case + random-field parity."""
+    Ng = (14, 12, 10)
+    u = rnd(Ng + (3,), T, 90)
+    ud = field(u, 3)
+    po, pd = O.zeros(Ng, T), field(O.zeros(Ng, T), 3)
+    cases = [("ke", {}), ("ke", dict(par=(0.3, -0.2, 0.1))), ("curl", dict(i=0)), ("curl", dict(i=1)), ("curl", dict(i=2)),
+             ("omega_mag", {}), ("omega_theta", dict(par=(0, 0, 1), par2=(5.0, 6.5, 3.0))), ("lambda2", {})]
+    for kind, kw in cases:
+        O.metric(po, kind, u, **kw)
+        S.metric(pd, kind, ud, **kw)
+        tol = 0 if kind in ("ke", "curl") else (2e-5 if T == np.float32 else 1e-11)
+        same(pd, po, exact=(tol == 0), tol=tol)
+    u2 = rnd((16, 12, 2), T, 91)                       # 2-D: ke and the out-of-plane curl
+    ud2, po2, pd2 = field(u2, 2), O.zeros((16, 12), T), field(O.zeros((16, 12), T), 2)
+    for kind, kw in (("ke", {}), ("curl", dict(i=2))):
+        same(S.metric(pd2, kind, ud2, **kw), O.metric(po2, kind, u2, **kw))

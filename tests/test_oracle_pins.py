@@ -345,3 +345,19 @@ def test_viscous_force_and_pressure_moment():
         O.apply_scalar(lambda x: x[1], p)
         m = O.pressure_moment_band((N / 2,) * D, p, df, idx, nds)                                # :365-368
         assert np.allclose(m, 0, atol=1e-8 * N ** D)
+
+
+def test_field_metrics():  # maintests.jl:319-339
+    J = (1, 2, 3)                                   # CartesianIndex(2,3,4)
+    x = np.array(J) + 1 - 1.5
+    px = np.prod(x)
+    u = O.zeros((3, 4, 5, 3), np.float64)
+    O.apply_vec(lambda i, xx: xx[i] + xx[0] * xx[1] * xx[2], u)
+    p = O.zeros((3, 4, 5), np.float64)
+    assert O.metric(p, "ke", u)[J] == 0.5 * np.sum((x + px) ** 2)
+    assert O.metric(p, "ke", u, par=x)[J] == 1.5 * px ** 2
+    assert abs(O.metric(p, "lambda2", u)[J] - 1) < 1e-12
+    w = np.cross(1 / x, np.repeat(px, 3))
+    assert O.metric(p, "curl", u, i=1)[J] == w[1]
+    assert abs(O.metric(p, "omega_mag", u)[J] - np.sqrt(np.sum(w ** 2))) < 1e-12
+    assert abs(O.metric(p, "omega_theta", u, par=(0, 0, 1), par2=x + np.array([0, 1, 2]))[J] - w[0]) < 1e-12

@@ -123,6 +123,7 @@ def lib() -> C.CDLL:
         "wl_flow_update": (i, [vp]),
         "wl_project": (i, [vp, vp, d, d, ip]),
         "wl_mom_step": (i, [vp, vp, d, dp, dp, dp, dp, ip]),
+        "wl_metric": (i, [i, gp, i, vp, vp, i, dp, dp]),
         "wl_pforce": (i, [i, gp, vp, vp, vp, i64, dp]),
         "wl_vforce": (i, [i, gp, vp, vp, vp, i64, d, dp]),
         "wl_pmoment": (i, [i, gp, vp, vp, vp, i64, dp, dp]),

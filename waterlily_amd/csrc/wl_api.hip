@@ -379,6 +379,82 @@ static int bdim_full(const G &g, T *u, const T *u0, T *f, const T *V, const T *m
     WL_TRY((op_bdim1<T, D>(g, f, u0, V, dt)));
     return op_bdim2<T, D, 0>(g, u, f, V, mu0, mu1);
 }
+// middle eigenvalue of a symmetric 3x3 matrix (closed form, Smith 1961) -- lambda2 = eigvals(Hermitian(S^2+O^2))[2]
+__host__ __device__ inline double sym3_mid_eig(double a00, double a01, double a02, double a11, double a12, double a22) {
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    const double q = (a00 + a11 + a22) / 3.0;
+    if (p1 == 0.0) {   // diagonal
+        double x = a00, y = a11, z = a22, t;
+        if (x > y) { t = x; x = y; y = t; }
+        if (y > z) { t = y; y = z; z = t; }
+        if (x > y) { t = x; x = y; y = t; }
+        return y;
+    }
+    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+    const double p = sqrt(p2 / 6.0);
+    const double c00 = b00 / p, c11 = b11 / p, c22 = b22 / p, c01 = a01 / p, c02 = a02 / p, c12 = a12 / p;
+    double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    const double phi = acos(r) / 3.0;
+    const double e1 = q + 2.0 * p * cos(phi), e3 = q + 2.0 * p * cos(phi + 2.0943951023931953);
+    return 3.0 * q - e1 - e3;
+}
+template <class T, int D>
+static int op_metric(const G &g, int kind, T *out, const T *u, int ipar, const double *par, const double *par2) {
+    const G gg = g;
+    double p3[3] = {0, 0, 0}, q3[3] = {0, 0, 0};
+    if (par) for (int d = 0; d < D; ++d) p3[d] = par[d];
+    if (par2) for (int d = 0; d < D; ++d) q3[d] = par2[d];
+    const double p0 = p3[0], p1 = p3[1], p2 = p3[2], q0 = q3[0], q1 = q3[1], q2 = q3[2];
+    return launch_range(WL_K_MISC, r_inside(g), [=] __device__(int i, int j, int k) {
+        const long I = gg.at(i, j, k);
+        const long S[3] = {gg.s[0], gg.s[1], gg.s[2]};
+        const long SC = gg.sc;
+        auto U = [&](int c, long off) -> T { return u[I + off + (long)c * SC]; };
+        auto dudx = [&](int a, int b) -> T {   // Metrics.jl:28-31
+            if (a == b) return U(a, S[a]) - U(a, 0);
+            return (U(a, S[b]) + U(a, S[b] + S[a]) - U(a, -S[b]) - U(a, -S[b] + S[a])) / (T)4;
+        };
+        T res = 0;
+        if (kind == WL_M_KE) {   // Metrics.jl:20-22
+            const double UU[3] = {p0, p1, p2};
+            double s = 0;   // (Float64 accumulation: exact for the reference's Float64 U, >= its precision for U=0)
+            for (int c = 0; c < D; ++c) { const double v = (double)(T)(U(c, 0) + U(c, S[c])) - 2.0 * UU[c]; s += v * v; }
+            res = (T)(0.125 * s);
+        } else if (kind == WL_M_CURL) {   // Metrics.jl:54: permute((j,k)->d(j,CI(I,k),u), i), backward differences
+            const int a = (ipar + 1) % 3, b = (ipar + 2) % 3;
+            res = (U(b, 0) - U(b, -S[a])) - (U(a, 0) - U(a, -S[b]));
+        } else if (D == 3) {
+            T w[3];
+            for (int c = 0; c < 3; ++c) { const int a = (c + 1) % 3, b = (c + 2) % 3; w[c] = dudx(b, a) - dudx(a, b); }   // Metrics.jl:60
+            if (kind == WL_M_OMAG) {
+                res = (T)sqrt((double)(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]));
+            } else if (kind == WL_M_OTHETA) {   // Metrics.jl:72-76
+                const double x[3] = {(double)i - 0.5 - q0, (double)j - 0.5 - q1, (double)(k + gg.kz0) - 0.5 - q2};
+                const double th[3] = {p1 * x[2] - p2 * x[1], p2 * x[0] - p0 * x[2], p0 * x[1] - p1 * x[0]};
+                const double n = sqrt(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+                res = n <= 2.220446049250313e-16 * n ? (T)0 : (T)((th[0] * (double)w[0] + th[1] * (double)w[1] + th[2] * (double)w[2]) / n);
+            } else {   // lambda2, Metrics.jl:41-45
+                double J[3][3], M[3][3];
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) J[a][b] = (double)dudx(a, b);
+                for (int a = 0; a < 3; ++a)
+                    for (int b = a; b < 3; ++b) {
+                        double m = 0;
+                        for (int c = 0; c < 3; ++c) {
+                            const double sa = 0.5 * (J[a][c] + J[c][a]), sb = 0.5 * (J[c][b] + J[b][c]);
+                            const double oa = 0.5 * (J[a][c] - J[c][a]), ob = 0.5 * (J[c][b] - J[b][c]);
+                            m += sa * sb + oa * ob;
+                        }
+                        M[a][b] = m;
+                    }
+                res = (T)sym3_mid_eig(M[0][0], M[0][1], M[0][2], M[1][1], M[1][2], M[2][2]);
+            }
+        }
+        out[I] = res;
+    });
+}
+
 // du_i/dx_j at the centre of cell I (src/Metrics.jl:28-31), in T
 template <class T> __device__ inline T dudx(const G &g, const T *u, long I, int i, int j) {
     const T *ui = u + (long)i * g.sc;
@@ -827,6 +903,13 @@ int wl_pmoment(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx, 
         if (t == WL_F32) hipLaunchKernelGGL(k_pmoment<float>, dim3(nb), dim3(256), 0, ctx().stream, gg, (const float *)p, idx, nds, nband, a, b, c, S.partials);
         else hipLaunchKernelGGL(k_pmoment<double>, dim3(nb), dim3(256), 0, ctx().stream, gg, (const double *)p, idx, nds, nband, a, b, c, S.partials);
     });
+}
+int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, int ipar, const double par[3],
+              const double par2[3]) {
+    WL_GS();
+    if (kind < 0 || kind > WL_M_LAMBDA2 || (kind >= WL_M_OMAG && g->D != 3) || (kind == WL_M_CURL && (ipar < 0 || ipar > 2)))
+        return fail(WL_E_ARG, "wl_metric: bad kind/component for this dimension", __FILE__, __LINE__);
+    WL_DISPATCH(t, g->D, (op_metric<T, DD>(gg, kind, (T *)out, (const T *)u, ipar, par, par2)));
 }
 int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx, const double *nds, int64_t nband,
               double out[3]) {

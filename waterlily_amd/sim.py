@@ -677,6 +677,23 @@ def band_to_device(p: torch.Tensor, idx: np.ndarray, nds: np.ndarray):
             torch.from_numpy(np.ascontiguousarray(nds, dtype=np.float64)).to(p.device))
 
 
+# --------------------------------------------------------------------------- Metrics.jl field metrics
+
+_METRIC = {"ke": 0, "curl": 1, "omega_mag": 2, "omega_theta": 3, "lambda2": 4}
+
+
+def metric(out: torch.Tensor, kind: str, u: torch.Tensor, i: int = 0, par=None, par2=None) -> torch.Tensor:
+    """`@inside out[I] = ke(I,u,U) | curl(i,I,u) | ω_mag(I,u) | ω_θ(I,z,center,u) | λ₂(I,u)` (src/Metrics.jl:14-77).
+    kind in {"ke","curl","omega_mag","omega_theta","lambda2"}; i = 0-based curl component; par = U (ke) or z (ω_θ),
+    par2 = center (ω_θ)."""
+    if tuple(u.shape[:-1]) != tuple(out.shape) or u.stride()[:-1] != out.stride():
+        raise ValueError("out and u must share the grid layout")
+    g = _grid_of(out, out.ndim)
+    check(_lib.lib().wl_metric(_WLT[_T(out)], C.byref(g), _METRIC[kind], _ptr(out), _ptr(u), int(i),
+                               None if par is None else d3(par), None if par2 is None else d3(par2)))
+    return out
+
+
 def _band_of(sim: Simulation):
     """(idx, nds) device tensors of the |d|<=1 band at the current flow time (cached per time)"""
     _ensure_band(sim)
