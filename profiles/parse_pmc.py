@@ -30,9 +30,19 @@ S7 = {"op_pcg": "pcg_mult_dot", "op_increment": "increment", "op_residual": "res
       "op_prolong_increment_fused": "smooth_prolong"}
 
 
+ROWVEC = {("op_pcg", "#1"): "pcg_init", ("op_pcg", "#2"): "pcg_update", ("op_pcg", "#3"): "pcg_direction",
+          ("op_bdim2", "#1"): "bdim", ("op_scale_all", "#1"): "scale"}
+
+
 def classify(name):
     if "k_convdiff3" in name:
         return "conv_diff"
+    if "k_correct3" in name:
+        return "correct"
+    if "k_rowvec" in name:
+        m = re.search(r"(op_\w+?)<", name)
+        o = re.search(r"#(\d)\}", name)
+        return ROWVEC.get((m.group(1), "#" + o.group(1))) if m and o else None
     if "k_stencil7" in name:
         m = re.search(r"(op_\w+?)<", name)
         return S7.get(m.group(1)) if m else None

@@ -11,7 +11,7 @@ import sys
 def short(n):
     if "k_convdiff3" in n:
         return "conv_diff(lds)"
-    m = re.search(r"(k_stencil7|k_range_red|k_range|k_finalize|k_reduce_only|k_apply)<.*?(op_\w+?|red_\w+?)<", n)
+    m = re.search(r"(k_stencil7|k_rowvec|k_range_red|k_range|k_finalize|k_reduce_only|k_apply)<.*?(op_\w+?|red_\w+?)<", n)
     if m:
         lam = re.search(r"#(\d)\}", n)
         return f"{m.group(2)}{'#' + lam.group(1) if lam else ''}[{m.group(1)[2:]}]"
