@@ -225,7 +225,9 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  *        (set before wl_mg_create; measured: no gain at 512^3, slower at 256^3), 0 = scalar range kernels
  * key 6: 1 = multigrid levels <= 4096 cells run as one single-workgroup launch per V-cycle (default), 0 = per-op launches
  * key 7: 1 = BC! as one closed-form launch (default), 0 = the reference's sequence of plane loops
- * key 4: rows per workgroup of the vectorised 7-point kernel: 0 = 4 rows / 256 threads (default), 1 = 8 rows / 512 */
+ * key 4: rows per workgroup of the vectorised 7-point kernel: 0 = 4 rows / 256 threads (default), 1 = 8 rows / 512
+ * key 8: 1 = pcg! applies x += alpha*eps in the direction kernel instead of the update kernel (default; one array
+ *        pass less per iteration, identical values), 0 = in the update kernel as the reference orders it */
 int wl_set_option(int key, int value);
 
 /* ------------------------------------------------------------------ measurement support */

@@ -211,6 +211,39 @@ def test_pcg_vcycle_solver(T, Ng):
 
 
 @pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("padded", [True, False])
+@pytest.mark.parametrize("xdefer", [1, 0])
+def test_pcg_exit_right_after_update(T, padded, xdefer):
+    """pcg! leaving through Poisson.jl:138 (|rho2| < 10eps straight after an update).  The x update of that iteration
+    still has to land: the default kernels apply it in the direction kernel (wl_set_option(8)), which must run for
+    exactly that owed update and nothing else.  Fully periodic unit-coefficient system, plane-wave residual: the
+    Jacobi-preconditioned direction is an eigenvector, so one iteration solves it."""
+    Ng, D = (18, 18, 18), 3
+    perdir = (0, 1, 2)
+    L = np.ones(Ng + (D,), T, order="F")
+    O.BC(L, (0.0,) * D, False, perdir)
+    i = np.arange(Ng[0], dtype=np.float64)
+    wave = np.cos(2 * np.pi * (i - 1) / (Ng[0] - 2))
+    r = np.asfortranarray(np.broadcast_to(wave[:, None, None], Ng).astype(T))
+    x = rnd(Ng, T, 77)
+    z = O.zeros(Ng, T)
+    po = O.Poisson(x.copy(order="F"), L.copy(order="F"), z.copy(order="F"), perdir=perdir)
+    ph = S.Poisson(field(x, D, padded), field(L, D, padded), field(z, D, padded), perdir=perdir)
+    po.r[...] = r
+    S.upload(lev_h(ph).r, r)
+    S.set_option(8, xdefer)
+    try:
+        n_o, n_h = O.pcg(po), S.pcg(ph)
+    finally:
+        S.set_option(8, 1)
+    assert n_o == n_h == 1                              # one (x,r) update, then the :138 return
+    ins = O.inside(x)
+    assert np.abs(po.x[ins] - x[ins]).max() > 0.1       # and x really moved
+    same(ph.x, po.x, exact=False, tol=rtol(T))
+    same(lev_h(ph).r, lev_o(po).r, exact=False, tol=rtol(T))
+
+
+@pytest.mark.parametrize("T", TYPES)
 def test_single_level_poisson_solver(T):
     po, ph = make_pois((18, 18), T, O.Poisson, S.Poisson)
     O.solver(po)

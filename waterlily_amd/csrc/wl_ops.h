@@ -23,6 +23,7 @@ struct State {
     int do_shift;             // residual! must subtract the mean
     int nupd;                 // number of (x,r) updates pcg performed
     int r2_valid;             // the last pcg! update already produced r.r (solver! can skip the separate L2 pass)
+    int xpend;                // pcg stopped at :138 with x += alpha*eps still owed (deferred-x form, see op_pcg)
 };
 
 template <class T> struct LevelT {
@@ -811,6 +812,10 @@ _Pragma("unroll")
 // device flag: once `active` drops, the remaining (already enqueued) kernels are no-ops, so no host sync.
 // Fusions: [mult + z.eps], [x,r update + z=r*iD + r.z], [direction]; identical per-cell arithmetic.
 // want_r2: the caller (solver!) needs L2(p) = r.r right after this call; it is accumulated by the last update kernel.
+// Deferred x (wl_set_option(8), default on): in iterations 1..it-1 the update x += alpha*eps (:133) moves from the
+// update kernel into the direction kernel that follows it (which streams eps anyway): one array pass less per
+// iteration (10T instead of 11T for update+direction).  Same per-cell expression, alpha unchanged in between; the :138
+// exit leaves st->xpend so that the direction kernel still applies the owed x update and nothing else.
 // scratch (optional): a level-sized buffer laid out like p.eps; when given (and the vector kernels apply, no periodic
 // direction, level not decomposed) iterations 2..it use the FUSED direction+mult kernel: eps_new = beta*eps + r*iD is
 // evaluated on the fly at the 7 stencil points and written out of place (eps <-> scratch ping-pong), z = r*iD is never
@@ -829,6 +834,7 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     const bool fusedir = vec && scratch && permask == 0 && !p.g.dist && ctx().opt[5] == 1 && ctx().opt[0] && stencil7_ok<T>(p.g, scratch, p.L) &&
                          (long)((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 7) / 4) + 8 <= WL_MAXB;
     T *ecur = p.eps, *eoth = scratch;   // (fusedir) buffer holding the current / next search direction
+    const bool xdef = ctx().opt[8] != 0 && !fusedir;
     // :125-127
     int rv0 = -1;
     if (vec) {
@@ -854,6 +860,7 @@ _Pragma("unroll")
         st->rho = (double)rho;
         st->nupd = 0;
         st->r2_valid = 0;
+        st->xpend = 0;
         st->active = !((rho < 0 ? -rho : rho) < eps10);
     })));
     for (int n = 1; n <= it; ++n) {
@@ -896,6 +903,7 @@ _Pragma("unroll")
             acc[0] += (double)v * (double)q.eps[I];
         }, partials, RED_SUM, 0.0, &np)));
         WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
+            st->xpend = 0;   // any owed x update was applied by the direction kernel before this mult
             if (!st->active) return;
             const T alpha = (T)st->rho / (T)v[0];
             const double aa = (double)(alpha < 0 ? -alpha : alpha);
@@ -903,17 +911,24 @@ _Pragma("unroll")
             if (aa < 1e-2 || aa > 1e2) st->active = 0;  // :132
         })));
         const bool last = (n == it);
+        const bool xnow = last || !xdef;   // x += alpha*eps in the update kernel (else in the direction kernel)
         // :133-137
         int rvu = -1;
         if (vec) {
             rvu = launch_rowvec<T, 1>(WL_K_PCG_UPDATE, p.g, [=] __device__(long o, int, int, double *acc) {
                 if (!st->active) return;
                 const T alpha = (T)st->alpha;
-                VA xv = VA::load(q.x + o), rr = VA::load(q.r + o);
-                const VA ev = VA::load(ecur + o), zv = VA::load(q.z + o);
+                VA rr = VA::load(q.r + o);
+                const VA zv = VA::load(q.z + o);
+                if (xnow) {
+                    VA xv = VA::load(q.x + o);
+                    const VA ev = VA::load(ecur + o);
 _Pragma("unroll")
-                for (int v = 0; v < VA::V; ++v) { xv.v[v] += alpha * ev.v[v]; rr.v[v] = rr.v[v] - alpha * zv.v[v]; }
-                xv.store(q.x + o);
+                    for (int v = 0; v < VA::V; ++v) xv.v[v] += alpha * ev.v[v];
+                    xv.store(q.x + o);
+                }
+_Pragma("unroll")
+                for (int v = 0; v < VA::V; ++v) rr.v[v] = rr.v[v] - alpha * zv.v[v];
                 rr.store(q.r + o);
                 if (!last) {
                     const VA id = VA::load(q.iD + o);
@@ -933,7 +948,7 @@ _Pragma("unroll")
             if (!st->active) return;
             const long I = q.g.at(i, j, k);
             const T alpha = (T)st->alpha;
-            q.x[I] += alpha * q.eps[I];
+            if (xnow) q.x[I] += alpha * q.eps[I];
             const T rn = q.r[I] - alpha * q.z[I];
             q.r[I] = rn;
             if (!last) {
@@ -953,7 +968,7 @@ _Pragma("unroll")
                 return;
             }
             const T rho2 = (T)v[0];
-            if ((rho2 < 0 ? -rho2 : rho2) < eps10) { st->active = 0; return; }  // :138
+            if ((rho2 < 0 ? -rho2 : rho2) < eps10) { st->active = 0; st->xpend = !xnow; return; }  // :138
             st->beta = (double)(rho2 / (T)st->rho);
             st->rho = (double)rho2;
         })));
@@ -963,9 +978,18 @@ _Pragma("unroll")
         int rvd = -1;
         if (vec) {
             rvd = launch_rowvec<T, 0>(WL_K_PCG_DIR, p.g, [=] __device__(long o, int, int, double *) {
-                if (!st->active) return;
-                const T beta = (T)st->beta;
+                const int act = st->active;
+                if (!act && !(xdef && st->xpend)) return;
                 VA ev = VA::load(q.eps + o);
+                if (xdef) {   // :133, deferred from the update kernel
+                    const T alpha = (T)st->alpha;
+                    VA xv = VA::load(q.x + o);
+_Pragma("unroll")
+                    for (int v = 0; v < VA::V; ++v) xv.v[v] += alpha * ev.v[v];
+                    xv.store(q.x + o);
+                    if (!act) return;
+                }
+                const T beta = (T)st->beta;
                 const VA zv = VA::load(q.z + o);
 _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) ev.v[v] = beta * ev.v[v] + zv.v[v];
@@ -975,8 +999,13 @@ _Pragma("unroll")
         }
         if (rvd != 0)
         WL_TRY(launch_range(WL_K_PCG_DIR, R, [=] __device__(int i, int j, int k) {
-            if (!st->active) return;
+            const int act = st->active;
+            if (!act && !(xdef && st->xpend)) return;
             const long I = q.g.at(i, j, k);
+            if (xdef) {
+                q.x[I] += (T)st->alpha * q.eps[I];
+                if (!act) return;
+            }
             q.eps[I] = (T)st->beta * q.eps[I] + q.z[I];
         }));
     }

@@ -502,6 +502,11 @@ def Jacobi(p, it=1, level=0):
     check(_lib.lib().wl_mg_jacobi(p._h, level, it))
 
 
+def set_option(key: int, value: int):
+    """Tuning / A-B switches of the library (include/wlhip.h, wl_set_option)."""
+    check(_lib.lib().wl_set_option(int(key), int(value)))
+
+
 def pcg(p, it=6, level=0) -> int:
     n = C.c_int()
     check(_lib.lib().wl_mg_pcg(p._h, level, it, C.byref(n)))
