@@ -145,6 +145,9 @@ int wl_mg_create(wl_mg **out, wl_dtype t, int nlevels, const wl_level_desc *leve
 int wl_mg_destroy(wl_mg *m);
 /* update!(ml)                         src/MultiLevelPoisson.jl:62-68 (src/Poisson.jl:46 for one level) */
 int wl_mg_update(wl_mg *m);
+/* Introspection: how many interior x-rows of `level` carry one coefficient value on all their faces (the 7-point kernels
+ * skip the loads of L there, see wl_set_option key 9) out of how many owned interior rows.  0 for D==2. */
+int wl_mg_uniform_rows(wl_mg *m, int level, long long *n_uniform, long long *n_rows);
 /* mult!(p,x): p.z = A x               src/Poisson.jl:62-68 */
 int wl_mg_mult(wl_mg *m, int level, void *x);
 /* residual!(p)                        src/Poisson.jl:91-97 */
@@ -227,7 +230,9 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  * key 7: 1 = BC! as one closed-form launch (default), 0 = the reference's sequence of plane loops
  * key 4: rows per workgroup of the vectorised 7-point kernel: 0 = 4 rows / 256 threads (default), 1 = 8 rows / 512
  * key 8: 1 = pcg! applies x += alpha*eps in the direction kernel instead of the update kernel (default; one array
- *        pass less per iteration, identical values), 0 = in the update kernel as the reference orders it */
+ *        pass less per iteration, identical values), 0 = in the update kernel as the reference orders it
+ * key 9: 1 = the 7-point kernels skip the loads of L in rows whose face coefficients are all one number (rows clear
+ *        of the body and the domain faces; constants recorded by wl_mg_update) (default), 0 = always load L */
 int wl_set_option(int key, int value);
 
 /* ------------------------------------------------------------------ measurement support */

@@ -243,6 +243,56 @@ def test_pcg_exit_right_after_update(T, padded, xdefer):
     same(lev_h(ph).r, lev_o(po).r, exact=False, tol=rtol(T))
 
 
+def _blob_system(T, cls_o, cls_h, padded=True):
+    """Unit coefficients (as away from a body) with a block of random ones in the middle: most x-rows are
+    coefficient-uniform (the kernels skip the loads of L there), the rows through the block are not."""
+    Ng, D = (34, 34, 34), 3
+    L = np.ones(Ng + (D,), T, order="F")
+    L[:, 12:19, 14:22, :] = rnd((34, 7, 8, D), T, 41, 0.2, 1.0)
+    L[9:21, 5:8, 25:28, 0] = T(0.5)                     # x faces only, strictly inside a row
+    O.BC(L, (0.0,) * D, False, ())
+    x, z = rnd(Ng, T, 42), rnd(Ng, T, 43)
+    z -= z[O.inside(z)].mean().astype(T)
+    po = cls_o(x.copy(order="F"), L.copy(order="F"), z.copy(order="F"))
+    ph = cls_h(field(x, D, padded), field(L, D, padded), field(z, D, padded))
+    return po, ph, x
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_uniform_rows_are_skipped_exactly(T):
+    """wl_set_option(9): rows whose face coefficients are all one number use that number instead of loading L.
+    Same values => every operator is bit-identical with the switch on and off, and mult! stays bit-exact
+    against the oracle on every level (c = 1, 2, 4 ... down the hierarchy)."""
+    po, ph, x = _blob_system(T, O.MultiLevelPoisson, S.MultiLevelPoisson)
+    nu, nr = S.uniform_rows(ph, 0)
+    assert nr == 32 * 32 and 0.5 * nr < nu < nr          # the block's rows and the rows next to domain faces are not uniform
+    nu1, nr1 = S.uniform_rows(ph, 1)
+    assert nr1 == 16 * 16 and 0 < nu1 < nr1
+    assert float(S.to_host(ph.levels[1].L)[4, 3, 3, 1]) == 2.0   # restrictL!: 0.5*(1+1+1+1)
+    for lo, lh in zip(po.levels, ph.levels):
+        same(lh.L, lo.L)
+        same(lh.iD, lo.iD)
+    xd = field(x, 3, True)
+    O.mult(po, x)
+    S.mult(ph, xd)
+    same(ph.z, po.z)
+    # the whole solver, switch on vs off, on twin systems
+    _, ph0, _ = _blob_system(T, O.MultiLevelPoisson, S.MultiLevelPoisson)
+    S.set_option(9, 0)
+    try:
+        S.mult(ph0, field(x, 3, True))                   # same source term z = A x as the twin above
+        assert np.array_equal(S.to_host(ph0.z), S.to_host(ph.z))
+        S.solver(ph0)
+    finally:
+        S.set_option(9, 1)
+    S.solver(ph)
+    O.solver(po)
+    assert ph.n == ph0.n == po.n
+    assert np.array_equal(S.to_host(ph.x), S.to_host(ph0.x))
+    assert np.array_equal(S.to_host(lev_h(ph).r), S.to_host(lev_h(ph0).r))
+    same(ph.x, po.x, exact=False, tol=10 * rtol(T))
+
+
 @pytest.mark.parametrize("T", TYPES)
 def test_single_level_poisson_solver(T):
     po, ph = make_pois((18, 18), T, O.Poisson, S.Poisson)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Per-launch time of the finest-level kernel classes on the BASELINE sphere for several values of one
+wl_set_option key, in ONE process.  usage: sweep.py <size> <key> <v1> <v2> ... [--f64]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from waterlily_amd import _lib  # noqa: E402
+from waterlily_amd import sim as S  # noqa: E402
+
+argv = [a for a in sys.argv[1:] if a != "--f64"]
+T = np.float64 if "--f64" in sys.argv else np.float32
+size, key = int(argv[0]), int(argv[1])
+vals = [int(v) for v in argv[2:]]
+L = _lib.lib()
+sim = bench.sphere((size,) * 3, T)
+names = {L.wl_kernel_name(k).decode(): k for k in range(24)}
+for _ in range(int(os.environ.get("WL_PRESTEPS", "30"))):
+    S.sim_step(sim, remeasure=False)
+classes = os.environ.get("WL_CLASSES", "pcg_mult_dot,pcg_update,pcg_direction,smooth,residual").split(",")
+print(f"{size}^3 {T.__name__} option[{key}] sweep; ms per finest-level launch")
+print("value  " + "  ".join(f"{c:>13s}" for c in classes))
+for rep in range(2):
+    for v in vals:
+        _lib.check(L.wl_set_option(key, v))
+        row = []
+        for nm in classes:
+            _lib.check(L.wl_prof_reset())
+            _lib.check(L.wl_prof_select(names[nm], int(0.9 * size ** 3)))
+            S.sim_step(sim, remeasure=False)
+            nl, nc, ms = C.c_int64(), C.c_int64(), C.c_double()
+            _lib.check(L.wl_prof_timed(C.byref(nl), C.byref(nc), C.byref(ms)))
+            row.append(ms.value / max(1, nl.value))
+        _lib.check(L.wl_prof_select(-1, 0))
+        print(f"{v:5d}  " + "  ".join(f"{t:13.3f}" for t in row))

@@ -192,6 +192,17 @@ struct wl_mg {
     std::vector<wl_level_desc> lev;
     Scratch sc;
     std::vector<void *> scr_base, scr;   // one internal level-sized buffer per level (pcg! direction ping-pong)
+    std::vector<void *> rowc;            // per level: row constants of L and iD (k_lrow), 2 values per (j,k) row; D==3 only
+    int alloc_rowc() {
+        const size_t es = t == WL_F32 ? 4 : 8;
+        rowc.assign(nlev, nullptr);
+        for (int l = 0; l < nlev; ++l) {
+            const wl_grid &g = lev[l].g;
+            if (g.D != 3) continue;
+            WL_HIP(hipMalloc(&rowc[l], (size_t)g.n[1] * (size_t)g.n[2] * RC_N * es));
+        }
+        return 0;
+    }
     int alloc_scratch() {
         const size_t es = t == WL_F32 ? 4 : 8;
         scr_base.assign(nlev, nullptr);
@@ -211,7 +222,8 @@ struct wl_mg {
     }
     void free_scratch() {
         for (void *p : scr_base) if (p) (void)hipFree(p);
-        scr_base.clear(); scr.clear();
+        for (void *p : rowc) if (p) (void)hipFree(p);
+        scr_base.clear(); scr.clear(); rowc.clear();
     }
 };
 struct wl_flow {
@@ -230,6 +242,7 @@ template <class T> static LevelT<T> lvl(const wl_mg *m, int l) {
     LevelT<T> o;
     o.g = mkG(&d.g);
     o.L = (T *)d.L; o.D = (T *)d.D; o.iD = (T *)d.iD; o.x = (T *)d.x; o.eps = (T *)d.eps; o.r = (T *)d.r; o.z = (T *)d.z;
+    o.rowc = (ctx().opt[9] && l < (int)m->rowc.size()) ? (const T *)m->rowc[l] : nullptr;
     return o;
 }
 
@@ -239,6 +252,7 @@ template <class T, int D> static int mg_update(wl_mg *m) {
         LevelT<T> p = lvl<T>(m, 0);
         WL_TRY((op_set_diag<T, D>(p.g, p.D, p.iD, p.L)));
         WL_TRY((halo_exchange<T>(p.g, p.iD, 1, 1)));   // z-slab: the fused smoother evaluates r*iD in the halo planes
+        if (D == 3 && m->rowc[0]) WL_TRY((op_lrow<T>(p.g, p.L, p.iD, (T *)m->rowc[0])));
     }
     for (int l = 1; l < m->nlev; ++l) {
         LevelT<T> a = lvl<T>(m, l), b = lvl<T>(m, l - 1);
@@ -246,6 +260,7 @@ template <class T, int D> static int mg_update(wl_mg *m) {
         WL_TRY((coarse_L_finish<T, D>(a.g, a.L, b.g, m->permask)));
         WL_TRY((op_set_diag<T, D>(a.g, a.D, a.iD, a.L)));
         WL_TRY((halo_exchange<T>(a.g, a.iD, 1, 1)));
+        if (D == 3 && m->rowc[l]) WL_TRY((op_lrow<T>(a.g, a.L, a.iD, (T *)m->rowc[l])));
     }
     return 0;
 }
@@ -774,6 +789,7 @@ int wl_mg_create(wl_mg **out, wl_dtype t, int nlevels, const wl_level_desc *leve
     int rc = m->sc.init();
     if (rc) { delete m; return rc; }
     rc = m->alloc_scratch();
+    if (!rc) rc = m->alloc_rowc();
     if (rc) { m->free_scratch(); m->sc.release(); delete m; return rc; }
     rc = wl_mg_update(m);
     if (rc) { m->free_scratch(); m->sc.release(); delete m; return rc; }
@@ -816,6 +832,23 @@ int wl_mg_pcg(wl_mg *m, int level, int it, int *n_updates) {
     if (n_updates) {
         WL_TRY(m->sc.fetch());
         *n_updates = m->sc.hst->nupd;
+    }
+    return 0;
+}
+int wl_mg_uniform_rows(wl_mg *m, int level, long long *n_uniform, long long *n_rows) {
+    WL_LEVEL_OK();
+    if (!n_uniform || !n_rows) return fail(WL_E_ARG, "wl_mg_uniform_rows: null output", __FILE__, __LINE__);
+    const wl_grid &g = m->lev[level].g;
+    *n_uniform = 0;
+    *n_rows = (long long)(g.n[1] - 2) * (g.D == 3 ? (g.own_hi > 0 ? g.own_hi - g.own_lo + 1 : g.n[2] - 2) : 1);
+    if (g.D != 3 || level >= (int)m->rowc.size() || !m->rowc[level]) return 0;
+    const size_t es = m->t == WL_F32 ? 4 : 8, cnt = (size_t)g.n[1] * g.n[2] * RC_N;
+    std::vector<char> h(cnt * es);
+    WL_HIP(hipMemcpyAsync(h.data(), m->rowc[level], cnt * es, hipMemcpyDeviceToHost, ctx().stream));
+    WL_HIP(hipStreamSynchronize(ctx().stream));
+    for (size_t r = 0; r < cnt; r += RC_N) {
+        const double c = m->t == WL_F32 ? (double)reinterpret_cast<const float *>(h.data())[r] : reinterpret_cast<const double *>(h.data())[r];
+        if (c == c) ++*n_uniform;
     }
     return 0;
 }

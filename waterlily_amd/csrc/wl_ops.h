@@ -29,6 +29,7 @@ struct State {
 template <class T> struct LevelT {
     G g;
     T *L, *D, *iD, *x, *eps, *r, *z;
+    const T *rowc = nullptr;   // row constants of L / iD (wl_stencil7.h, k_lrow); nullptr = none (raw operator calls)
 };
 
 inline long span(const G &g) { return g.D == 3 ? (long)g.n[2] * g.s[2] : (long)g.n[1] * g.s[1]; }
@@ -376,7 +377,7 @@ int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu
         // evaluates the general statement on the busy rows only (coalesced per cell; ~5 % of the rows for a sphere)
         if (rowfree && stencil7_ok<T>(g, u, f)) {
             using VA = VecA<T>;
-            const int rc = launch_rowvec<T, 0>(WL_K_BDIM, g, [=] __device__(long o, int j, int k, double *) {
+            const int rc = launch_rowvec<T, 0>(WL_K_BDIM, g, [=] __device__(long o, int j, int k, double *, const Pre &) {
                 if (!rowfree[j + gg.n[1] * k]) return;
 _Pragma("unroll")
                 for (int c = 0; c < 3; ++c) {
@@ -645,8 +646,8 @@ int op_residual(const LevelT<T> &p, int permask, double *partials, State *st) {
     if constexpr (D == 3) {
         if (stencil7_ok<T>(p.g, p.x, p.L) && stencil7_ok<T>(p.g, p.r, p.iD) && stencil7_ok<T>(p.g, p.z, p.L)) {
             using VA = VecA<T>;
-            rcv = launch_stencil7<T, 1>(WL_K_RESIDUAL, p.g, SrcArray<T>{p.x}, p.L, [=] __device__(long o, const VA &ax, const VA &, double *acc) {
-                const VA id = VA::load(q.iD + o), zz = VA::load(q.z + o);
+            rcv = launch_stencil7p<T, 1>(WL_K_RESIDUAL, p.g, SrcArray<T>{p.x}, p.L, p.rowc, p.iD, p.z,
+                [=] __device__(long o, const VA &ax, const VA &, const VA &id, const VA &zz, double *acc, const Pre &) {
                 VA rv;
 _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) {
@@ -687,8 +688,9 @@ int op_increment(const LevelT<T> &p, int permask) {
     if constexpr (D == 3) {
         if (stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.r, p.x)) {
             using VA = VecA<T>;
-            const int rcv = launch_stencil7<T, 0>(WL_K_INCREMENT, p.g, SrcArray<T>{p.eps}, p.L, [=] __device__(long o, const VA &ae, const VA &ec, double *) {
-                VA rv = VA::load(q.r + o), xv = VA::load(q.x + o);
+            const int rcv = launch_stencil7p<T, 0>(WL_K_INCREMENT, p.g, SrcArray<T>{p.eps}, p.L, p.rowc, p.r, p.x,
+                [=] __device__(long o, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
+                VA rv = r0, xv = x0;
 _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
                 rv.store(q.r + o);
@@ -730,9 +732,9 @@ int op_smooth_fused(const LevelT<T> &p, T *rout) {
     if constexpr (D == 3) {
         if (stencil7_ok<T>(p.g, p.r, p.L) && stencil7_ok<T>(p.g, p.iD, p.x) && stencil7_ok<T>(p.g, rout, p.L)) {
             using VA = VecA<T>;
-            const int rcv = launch_stencil7<T, 0>(WL_K_SMOOTH, p.g, SrcJacobi<T>{p.r, p.iD}, p.L,
-                [=] __device__(long o, const VA &ae, const VA &ec, double *) {
-                    VA rv = VA::load(q.r + o), xv = VA::load(q.x + o);
+            const int rcv = launch_stencil7p<T, 0>(WL_K_SMOOTH, p.g, SrcJacobi<T>{p.r, p.iD, p.rowc, p.g.n[0], p.g.n[1]}, p.L, p.rowc,
+                p.r, p.x, [=] __device__(long o, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
+                    VA rv = r0, xv = x0;
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
                     rv.store(rout + o);
@@ -772,9 +774,9 @@ int op_prolong_increment_fused(const LevelT<T> &p, const T *rin, const G &gc, co
         if (stencil7_ok<T>(p.g, p.r, p.L) && stencil7_ok<T>(p.g, rin, p.x)) {
             using VA = VecA<T>;
             const SrcProlong<T> src{cx, C, p.g.n[0], p.g.n[1], p.g.nzg, p.g.kz0};
-            const int rcv = launch_stencil7<T, 0>(WL_K_SMOOTH, p.g, src, p.L,
-                [=] __device__(long o, const VA &ae, const VA &ec, double *) {
-                    VA rv = VA::load(rin + o), xv = VA::load(q.x + o);
+            const int rcv = launch_stencil7p<T, 0>(WL_K_SMOOTH, p.g, src, p.L, p.rowc, rin, p.x,
+                [=] __device__(long o, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
+                    VA rv = r0, xv = x0;
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
                     rv.store(q.r + o);
@@ -835,15 +837,19 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
                          (long)((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 7) / 4) + 8 <= WL_MAXB;
     T *ecur = p.eps, *eoth = scratch;   // (fusedir) buffer holding the current / next search direction
     const bool xdef = ctx().opt[8] != 0 && !fusedir;
+    // z' = r*iD (:136) is not stored (wl_set_option(13), default on): the direction kernel recomputes it from r and iD
+    // (iD is a row constant away from the body), one array write + one read less per iteration; z keeps A*eps.
+    const bool zrec = ctx().opt[13] != 0 && !fusedir;
     // :125-127
     int rv0 = -1;
     if (vec) {
-        rv0 = launch_rowvec<T, 1>(WL_K_PCG_INIT, p.g, [=] __device__(long o, int, int, double *acc) {
-            const VA rr = VA::load(q.r + o), id = VA::load(q.iD + o);
+        rv0 = launch_rowvec<T, 1>(WL_K_PCG_INIT, p.g, [=] __device__(long o, int j, int k, double *acc, const Pre &pre) {
+            const VA rr = VA::load(q.r + o);
+            const VA id = load_iD<T>(q.iD, q.rowc, q.g.n[0], q.g.n[1], o, (int)(o - q.g.s[1] * j - q.g.s[2] * k), j, k);
             VA zv;
 _Pragma("unroll")
             for (int v = 0; v < VA::V; ++v) { zv.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zv.v[v]; }
-            zv.store(q.z + o);
+            if (!zrec) zv.store(q.z + o);
             zv.store(q.eps + o);
         }, partials, &np);
         if (rv0 > 0) return rv0;
@@ -852,7 +858,8 @@ _Pragma("unroll")
     WL_TRY((launch_range_red<1>(WL_K_PCG_INIT, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
         const long I = q.g.at(i, j, k);
         const T v = q.r[I] * q.iD[I];
-        q.z[I] = v; q.eps[I] = v;
+        if (!zrec) q.z[I] = v;
+        q.eps[I] = v;
         acc[0] += (double)q.r[I] * (double)v;
     }, partials, RED_SUM, 0.0, &np)));
     WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
@@ -873,23 +880,22 @@ _Pragma("unroll")
                 if (fusedir && n > 1) {
                     // :140 of the previous iteration + :130-131: eps_new = beta*eps + r*iD (out of place), z = A eps_new
                     T *eo = eoth;
-                    rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g, SrcDirection<T>{ecur, p.r, p.iD, &st->beta}, p.L,
-                        [=] __device__(long o, const VA &ae, const VA &ec, double *acc) {
-                            if (!st->active) return;
+                    rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g, SrcDirection<T>{ecur, p.r, p.iD, &st->beta}, p.L, p.rowc,
+                        [=] __device__(long o, const VA &ae, const VA &ec, double *acc, const Pre &) {
                             ec.store(eo + o);
                             ae.store(q.z + o);
 _Pragma("unroll")
                             for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];
-                        }, partials, &np);
+                        }, partials, &np, Gate{&st->active});
                     if (rcv == 0) { T *tmp = ecur; ecur = eoth; eoth = tmp; }
                 } else {
                 const T *esrc = ecur;
-                rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g, SrcArray<T>{esrc}, p.L, [=] __device__(long o, const VA &ae, const VA &ec, double *acc) {
-                    if (!st->active) return;
+                rcv = launch_stencil7p<T, 1>(WL_K_PCG_MULT, p.g, SrcArray<T>{esrc}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
+                    [=] __device__(long o, const VA &ae, const VA &ec, const VA &, const VA &, double *acc, const Pre &) {
                     ae.store(q.z + o);
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];
-                }, partials, &np);
+                }, partials, &np, Gate{&st->active});
                 }
                 if (rcv > 0) return rcv;
             }
@@ -915,11 +921,12 @@ _Pragma("unroll")
         // :133-137
         int rvu = -1;
         if (vec) {
-            rvu = launch_rowvec<T, 1>(WL_K_PCG_UPDATE, p.g, [=] __device__(long o, int, int, double *acc) {
-                if (!st->active) return;
-                const T alpha = (T)st->alpha;
+            rvu = launch_rowvec<T, 1>(WL_K_PCG_UPDATE, p.g, [=] __device__(long o, int j, int k, double *acc, const Pre &pre) {
+                const T alpha = (T)pre.s0;
                 VA rr = VA::load(q.r + o);
                 const VA zv = VA::load(q.z + o);
+                VA id;   // every load of this plane is issued before its first store
+                if (!last) id = load_iD<T>(q.iD, q.rowc, q.g.n[0], q.g.n[1], o, (int)(o - q.g.s[1] * j - q.g.s[2] * k), j, k);
                 if (xnow) {
                     VA xv = VA::load(q.x + o);
                     const VA ev = VA::load(ecur + o);
@@ -931,16 +938,15 @@ _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) rr.v[v] = rr.v[v] - alpha * zv.v[v];
                 rr.store(q.r + o);
                 if (!last) {
-                    const VA id = VA::load(q.iD + o);
                     VA zn;
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) { zn.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zn.v[v]; }
-                    if (!fusedir) zn.store(q.z + o);   // fused direction+mult recomputes r*iD: z' is never stored
+                    if (!fusedir && !zrec) zn.store(q.z + o);   // (else) the direction kernel recomputes r*iD: z' is never stored
                 } else if (want_r2) {
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) acc[0] += (double)rr.v[v] * (double)rr.v[v];
                 }
-            }, partials, &np);
+            }, partials, &np, Gate{&st->active, nullptr, &st->alpha});
             if (rvu > 0) return rvu;
         }
         if (rvu != 0)
@@ -953,7 +959,7 @@ _Pragma("unroll")
             q.r[I] = rn;
             if (!last) {
                 const T zn = rn * q.iD[I];
-                q.z[I] = zn;
+                if (!zrec) q.z[I] = zn;
                 acc[0] += (double)rn * (double)zn;
             } else if (want_r2) {
                 acc[0] += (double)rn * (double)rn;
@@ -977,24 +983,31 @@ _Pragma("unroll")
         if (fusedir) continue;   // folded into the next iteration's mult kernel
         int rvd = -1;
         if (vec) {
-            rvd = launch_rowvec<T, 0>(WL_K_PCG_DIR, p.g, [=] __device__(long o, int, int, double *) {
-                const int act = st->active;
-                if (!act && !(xdef && st->xpend)) return;
+            rvd = launch_rowvec<T, 0>(WL_K_PCG_DIR, p.g, [=] __device__(long o, int j, int k, double *, const Pre &pre) {
+                // gate: runs when pcg is active, or (deferred x) when only the x update of the :138 exit is owed
                 VA ev = VA::load(q.eps + o);
+                VA xv, zv;
+                if (xdef) xv = VA::load(q.x + o);
+                if (pre.act) {
+                    if (zrec) {   // z' = r*iD (:136) recomputed
+                        const VA rr = VA::load(q.r + o);
+                        const VA id = load_iD<T>(q.iD, q.rowc, q.g.n[0], q.g.n[1], o, (int)(o - q.g.s[1] * j - q.g.s[2] * k), j, k);
+_Pragma("unroll")
+                        for (int v = 0; v < VA::V; ++v) zv.v[v] = rr.v[v] * id.v[v];
+                    } else zv = VA::load(q.z + o);
+                }
                 if (xdef) {   // :133, deferred from the update kernel
-                    const T alpha = (T)st->alpha;
-                    VA xv = VA::load(q.x + o);
+                    const T alpha = (T)pre.s0;
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) xv.v[v] += alpha * ev.v[v];
                     xv.store(q.x + o);
-                    if (!act) return;
                 }
-                const T beta = (T)st->beta;
-                const VA zv = VA::load(q.z + o);
+                if (!pre.act) return;
+                const T beta = (T)pre.s1;
 _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) ev.v[v] = beta * ev.v[v] + zv.v[v];
                 ev.store(q.eps + o);
-            }, nullptr, nullptr);
+            }, nullptr, nullptr, Gate{&st->active, xdef ? &st->xpend : nullptr, &st->alpha, &st->beta});
             if (rvd > 0) return rvd;
         }
         if (rvd != 0)
@@ -1006,7 +1019,7 @@ _Pragma("unroll")
                 q.x[I] += (T)st->alpha * q.eps[I];
                 if (!act) return;
             }
-            q.eps[I] = (T)st->beta * q.eps[I] + q.z[I];
+            q.eps[I] = (T)st->beta * q.eps[I] + (zrec ? q.r[I] * q.iD[I] : q.z[I]);
         }));
     }
     return 0;

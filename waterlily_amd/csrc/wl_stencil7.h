@@ -9,6 +9,10 @@
 //     touch memory for them; y neighbours are aligned vector loads of the rows above/below (L1/L2 hits: the
 //     neighbouring wave of the same workgroup streams that row);
 //   * the diagonal is recomputed from the six face coefficients (same operations as set_diag!, Poisson.jl:48-54);
+//   * coefficient-uniform rows: away from the body (and from the domain faces) every face coefficient of a row is
+//     the same number c (1 on the finest level, 2^l below: restrictL! sums four unit faces and halves).  wl_mg_update
+//     records c per row (NaN = not uniform, see k_lrow); in such a row the kernel does not load L at all (3 of the 5
+//     array passes of mult) and uses c -- the very values the loads would have returned, so results are unchanged;
 //   * an epilogue functor turns A e into the operator at hand: z=Ae & z.e (pcg!), r-=Ae & x+=e (increment!),
 //     r = z-Ax (residual!), with per-thread Float64 partials reduced exactly like the range kernels.
 // Per-cell arithmetic and its order are those of mult()/set_diag! => bit-identical to the generic kernels.
@@ -46,17 +50,77 @@ template <class T> struct SrcArray {          // e is an array (pcg!: eps, resid
     const T *e;
     __device__ __forceinline__ VecA<T> vec(long o, int, int, int) const { return VecA<T>::load(e + o); }
     __device__ __forceinline__ T scal(long o, int, int, int) const { return e[o]; }
+    // split form for the software-pipelined kernel: raw() only issues loads, cook() does the arithmetic (if any)
+    using Raw = VecA<T>;
+    using RawS = T;
+    __device__ __forceinline__ Raw raw(long o, int, int, int) const { return VecA<T>::load(e + o); }
+    __device__ __forceinline__ VecA<T> cook(const Raw &r) const { return r; }
+    __device__ __forceinline__ RawS raws(long o, int, int, int) const { return e[o]; }
+    __device__ __forceinline__ T cooks(const RawS &r) const { return r; }
 };
+// iD of the V cells at (i..i+V-1, j, k): the row constant where the row is coefficient-uniform (k_lrow; the two end
+// cells of a row are excluded from that guarantee, so the vectors holding them are loaded), else the array.
+// j and k must be wave-uniform (they are: a wavefront works on one row).
+// Row constants (k_lrow): RC_N values per x-row (j,k) of a level: [c, lxf, lxl, idc, idf, idl, -, -]
+//   c   = the one value of every face coefficient of the row (NaN: the row is not uniform, use the arrays),
+//   lxf, lxl = Lx at the two x-boundary faces (i = 1 and n0-1), idc = iD of the cells 2..n0-3, idf/idl = iD of the end cells.
+constexpr int RC_N = 8;
+template <class T> struct RowC { T c, lxf, lxl, idc; };
+template <class T> __device__ __forceinline__ RowC<T> load_rowc(const T *p) {
+    RowC<T> r;
+    if constexpr (sizeof(T) == 4) {
+        const VecA<T> a = VecA<T>::load(p);
+        r.c = a.v[0]; r.lxf = a.v[1]; r.lxl = a.v[2]; r.idc = a.v[3];
+    } else {
+        const VecA<T> a = VecA<T>::load(p), b = VecA<T>::load(p + 2);
+        r.c = a.v[0]; r.lxf = a.v[1]; r.lxl = b.v[0]; r.idc = b.v[1];
+    }
+    return r;
+}
+template <class T>
+__device__ __forceinline__ VecA<T> load_iD(const T *iD, const T *rowc, int n0, int n1, long o, int i, int j, int k) {
+    constexpr int V = VecA<T>::V;
+    if (rowc) {
+        const T *rc = rowc + RC_N * ((long)__builtin_amdgcn_readfirstlane(j) + (long)n1 * __builtin_amdgcn_readfirstlane(k));
+        const T c = rc[0];
+        if (c == c) {
+            const T idc = rc[3];
+            VecA<T> b;
+#pragma unroll
+            for (int v = 0; v < V; ++v) b.v[v] = idc;
+            if (i == 1) b.v[0] = rc[4];
+            if (i + V - 1 == n0 - 2) b.v[V - 1] = rc[5];
+            return b;
+        }
+    }
+    return VecA<T>::load(iD + o);
+}
+
 template <class T> struct SrcJacobi {         // e = r*iD evaluated on the fly (Jacobi!, src/Poisson.jl:111)
     const T *r, *iD;
-    __device__ __forceinline__ VecA<T> vec(long o, int, int, int) const {
-        const VecA<T> a = VecA<T>::load(r + o), b = VecA<T>::load(iD + o);
+    const T *rowc;                             // row constants (nullptr: none)
+    int n0, n1;
+    __device__ __forceinline__ VecA<T> vec(long o, int i, int j, int k) const {
+        const VecA<T> a = VecA<T>::load(r + o), b = load_iD<T>(iD, rowc, n0, n1, o, i, j, k);
         VecA<T> c;
 #pragma unroll
         for (int v = 0; v < VecA<T>::V; ++v) c.v[v] = a.v[v] * b.v[v];
         return c;
     }
     __device__ __forceinline__ T scal(long o, int, int, int) const { return r[o] * iD[o]; }
+    struct Raw { VecA<T> a, b; };
+    struct RawS { T a, b; };
+    __device__ __forceinline__ Raw raw(long o, int i, int j, int k) const {
+        return Raw{VecA<T>::load(r + o), load_iD<T>(iD, rowc, n0, n1, o, i, j, k)};
+    }
+    __device__ __forceinline__ VecA<T> cook(const Raw &q) const {
+        VecA<T> c;
+#pragma unroll
+        for (int v = 0; v < VecA<T>::V; ++v) c.v[v] = q.a.v[v] * q.b.v[v];
+        return c;
+    }
+    __device__ __forceinline__ RawS raws(long o, int, int, int) const { return RawS{r[o], iD[o]}; }
+    __device__ __forceinline__ T cooks(const RawS &q) const { return q.a * q.b; }
 };
 template <class T> struct SrcDirection {      // e = beta*eps + r*iD : pcg!'s new search direction on the fly (Poisson.jl:136,140)
     const T *e, *r, *iD;
@@ -93,12 +157,36 @@ template <class T> struct SrcProlong {        // e[I] = coarse x[down(I)] inside
         for (int v = 0; v < VecA<T>::V; v += 2) { const T p = row[(i + v + 1) / 2]; c.v[v] = p; c.v[v + 1] = p; }
         return c;
     }
+    using Raw = VecA<T>;
+    using RawS = T;
+    __device__ __forceinline__ Raw raw(long o, int i, int j, int k) const { return vec(o, i, j, k); }
+    __device__ __forceinline__ VecA<T> cook(const Raw &r) const { return r; }
+    __device__ __forceinline__ RawS raws(long o, int i, int j, int k) const { return scal(o, i, j, k); }
+    __device__ __forceinline__ T cooks(const RawS &r) const { return r; }
 };
 
+// Device-side gate and scalars of a solver kernel, read ONCE per thread before its z loop (uniform addresses): inside
+// the loop they would be re-loaded every plane (the stores in between may alias them as far as the compiler knows),
+// each time draining the loads in flight.  The body runs when no gate is given, when *active != 0, or when `also` is
+// given and *also != 0.  s0/s1: optional device scalars (alpha, beta) handed to the functor.
+struct Gate {
+    const int *active = nullptr, *also = nullptr;
+    const double *s0 = nullptr, *s1 = nullptr;
+};
+struct Pre { int act; double s0, s1; };
+__device__ __forceinline__ bool gate_open(const Gate &gt, Pre &pre) {
+    pre.act = 1; pre.s0 = 0.0; pre.s1 = 0.0;
+    bool run = true;
+    if (gt.active) { pre.act = *gt.active; run = pre.act || (gt.also && *gt.also); }
+    if (gt.s0) pre.s0 = *gt.s0;
+    if (gt.s1) pre.s1 = *gt.s1;
+    return run;
+}
+
 template <class T, int NRED, int BY, class SRC, class EPI>
-__global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__restrict__ L, EPI epi,
+__global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__restrict__ L, const T *__restrict__ rowc, EPI epi,
                                                   double *partials, int ntx, int tpp, int nblk, int clen, int klo,
-                                                  int khi) {
+                                                  int khi, Gate gate) {
     constexpr int V = Vec16<T>::V;
     using VA = VecA<T>;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -112,23 +200,47 @@ __global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__r
     double acc[NRED > 0 ? NRED : 1];
 #pragma unroll
     for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) acc[q] = 0.0;
-    const bool active = (i <= nxi) && (j <= nyi) && (k0 < k1);
+    Pre pre;
+    const bool run = gate_open(gate, pre);
+    const bool active = run && (i <= nxi) && (j <= nyi) && (k0 < k1);
     if (active) {   // (no barriers below: inactive lanes may simply skip; shuffles only pair active lanes)
         const bool first = (lane == 0), last = (lane == 63) || (i + V > nxi);
         const long sy = g.s[1], sz = g.s[2], sc = g.sc;
         const long col = (long)i + sy * (long)j;
         const T *Lx = L, *Ly = L + sc, *Lz = L + 2 * sc;
+        // register window of e: planes k-1, k, k+1; plane k+2 is requested in iteration k and consumed in k+1, so that
+        // two planes of e are in flight per wavefront (in a coefficient-uniform row e is the only HBM stream)
         VA em = src.vec(col + sz * (k0 - 1), i, j, k0 - 1), ec = src.vec(col + sz * k0, i, j, k0);
+        VA ep = src.vec(col + sz * (k0 + 1), i, j, k0 + 1);
         VA lzc = VA::load(Lz + col + sz * k0);
+        const int ju = __builtin_amdgcn_readfirstlane(j);   // a wavefront works on ONE row: row constants are scalar loads
+        const T *rcp = rowc ? rowc + RC_N * ((long)ju + (long)g.n[1] * k0) : nullptr;
+        const long rcs = RC_N * (long)g.n[1];
+        T cn = rcp ? rcp[0] : (T)0;
         for (int k = k0; k < k1; ++k) {
             const long o = col + sz * k;
-            const VA ep = src.vec(o + sz, i, j, k + 1), lzp = VA::load(Lz + o + sz);
+            const T c = cn;
+            const bool uni = rcp && (c == c);
+            if (rcp) { rcp += rcs; cn = rcp[0]; }           // next plane's row constant (plane k1 <= n2-1 exists)
             const VA ym = src.vec(o - sy, i, j - 1, k), yp = src.vec(o + sy, i, j + 1, k);
-            const VA lx = VA::load(Lx + o), ly0 = VA::load(Ly + o), ly1 = VA::load(Ly + o + sy);
+            VA lx, ly0, ly1, lzp;
+            T lxr;
+            if (uni) {   // all faces of this row are c, except possibly the two x-boundary faces (read by the end lanes)
+#pragma unroll
+                for (int v = 0; v < V; ++v) { lx.v[v] = c; ly0.v[v] = c; ly1.v[v] = c; lzp.v[v] = c; }
+                if (i == 1) lx.v[0] = Lx[o];
+                lxr = c;
+            } else {
+                lx = VA::load(Lx + o); ly0 = VA::load(Ly + o); ly1 = VA::load(Ly + o + sy); lzp = VA::load(Lz + o + sz);
+                lxr = __shfl_down(lx.v[0], 1, 64);
+            }
             // x neighbours of the vector ends: adjacent lane, or memory at the two ends of the row segment
-            T left = __shfl_up(ec.v[V - 1], 1, 64), right = __shfl_down(ec.v[0], 1, 64), lxr = __shfl_down(lx.v[0], 1, 64);
+            T left = __shfl_up(ec.v[V - 1], 1, 64), right = __shfl_down(ec.v[0], 1, 64);
             if (first) left = src.scal(o - 1, i - 1, j, k);
             if (last) { right = src.scal(o + V, i + V, j, k); lxr = Lx[o + V]; }
+            // issued last: nothing in this iteration waits for it (plane k1 is the last one that exists for this chunk)
+            const int kn = (k + 2 <= k1) ? k + 2 : k1;
+            const VA en = src.vec(col + sz * kn, i, j, kn);
             VA ae;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
@@ -145,8 +257,121 @@ __global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__r
                 s += em.v[v] * lzc.v[v] + ep.v[v] * lzp.v[v];
                 ae.v[v] = s;
             }
-            epi(o, ae, ec, acc);
-            em = ec; ec = ep; lzc = lzp;
+            epi(o, ae, ec, acc, pre);
+            em = ec; ec = ep; ep = en; lzc = lzp;
+        }
+    }
+    if (NRED > 0) {
+        block_red<(NRED > 0 ? NRED : 1), BY>(acc, RED_SUM);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 0; q < NRED; ++q) partials[(long)q * gridDim.x + blockIdx.x] = acc[q];
+        }
+    }
+}
+
+// ---- software-pipelined form of k_stencil7 (the default).  Same arithmetic; what changes is WHEN loads are issued.
+// In the plain kernel every plane's loads are consumed in the iteration that issues them, so each wavefront sits
+// out one memory latency per plane and the achieved rate is (occupancy x bytes per plane) / latency, well under the
+// HBM rate once L is skipped.  Here iteration k only ISSUES the loads of later planes -- e at k+2, the rows j-1/j+1,
+// the edge scalars, the row constants and the two epilogue operands (ea, eb: e.g. r and x of increment!) at k+1 --
+// and consumes values requested one iteration earlier.  Sources expose raw() (loads only) and cook() (arithmetic)
+// so that e.g. r*iD of the Jacobi source is formed when the operands are used, not when they are requested.
+// EPI(o, Ae, e, a, b, acc, pre): a, b = the V values of ea, eb at o (undefined when the pointer is null).
+template <class T, int NRED, int BY, class SRC, class EPI>
+__global__ __launch_bounds__(64 * BY) void k_stencil7p(G g, SRC src, const T *__restrict__ L, const T *__restrict__ rowc,
+                                                   const T *ea, const T *eb, EPI epi, double *partials, int ntx, int tpp,
+                                                   int nblk, int clen, int klo, int khi, Gate gate) {
+    constexpr int V = Vec16<T>::V;
+    using VA = VecA<T>;
+    using Raw = typename SRC::Raw;
+    using RawS = typename SRC::RawS;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);   // XCD-contiguous logical id
+    const int ch = lb / tpp, pt = lb - ch * tpp;
+    const int nxi = g.n[0] - 2, nyi = g.n[1] - 2;
+    const int i = 1 + (pt % ntx) * 64 * V + lane * V;
+    const int j = 1 + (pt / ntx) * BY + wv;
+    const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);
+    double acc[NRED > 0 ? NRED : 1];
+#pragma unroll
+    for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) acc[q] = 0.0;
+    Pre pre;
+    const bool run = gate_open(gate, pre);
+    const bool active = run && (i <= nxi) && (j <= nyi) && (k0 < k1);
+    if (active) {
+        const bool first = (lane == 0), last = (lane == 63) || (i + V > nxi);
+        const long sy = g.s[1], sz = g.s[2], sc = g.sc;
+        const long col = (long)i + sy * (long)j;
+        const T *Lx = L, *Ly = L + sc, *Lz = L + 2 * sc;
+        const long o0 = col + sz * k0;
+        VA em = src.cook(src.raw(o0 - sz, i, j, k0 - 1)), ec = src.cook(src.raw(o0, i, j, k0));
+        Raw epr = src.raw(o0 + sz, i, j, k0 + 1);
+        Raw ymr = src.raw(o0 - sy, i, j - 1, k0), ypr = src.raw(o0 + sy, i, j + 1, k0);
+        RawS slr = src.raws(first ? o0 - 1 : o0, first ? i - 1 : i, j, k0);   // only the end lanes use theirs
+        RawS srr = src.raws(last ? o0 + V : o0, last ? i + V : i, j, k0);
+        VA ac = em, bc = em;
+        if (ea) ac = VA::load(ea + o0);
+        if (eb) bc = VA::load(eb + o0);
+        VA lzc = VA::load(Lz + o0);
+        const int ju = __builtin_amdgcn_readfirstlane(j);
+        const T *rcp = rowc ? rowc + RC_N * ((long)ju + (long)g.n[1] * k0) : nullptr;
+        const long rcs = RC_N * (long)g.n[1];
+        RowC<T> rcur;
+        rcur.c = rcur.lxf = rcur.lxl = rcur.idc = (T)0;
+        if (rcp) rcur = load_rowc<T>(rcp);
+        for (int k = k0; k < k1; ++k) {
+            const long o = col + sz * k;
+            // ---- requests (consumed in the next iteration; planes k+1 <= k1 and rows j-1, j+1 always exist)
+            const Raw ymn = src.raw(o + sz - sy, i, j - 1, k + 1), ypn = src.raw(o + sz + sy, i, j + 1, k + 1);
+            VA an = ac, bn = bc;
+            if (ea) an = VA::load(ea + o + sz);
+            if (eb) bn = VA::load(eb + o + sz);
+            RowC<T> rnext = rcur;
+            if (rcp) { rcp += rcs; rnext = load_rowc<T>(rcp); }
+            RawS sln = slr, srn = srr;
+            if (first) sln = src.raws(o + sz - 1, i - 1, j, k + 1);
+            if (last) srn = src.raws(o + sz + V, i + V, j, k + 1);
+            const int kn = (k + 2 <= k1) ? k + 2 : k1;   // plane k1 is the last one this chunk may touch
+            const Raw enr = src.raw(col + sz * kn, i, j, kn);
+            // ---- this plane
+            const VA ep = src.cook(epr), ym = src.cook(ymr), yp = src.cook(ypr);
+            const T c = rcur.c;
+            const bool uni = rowc && (c == c);
+            VA lx, ly0, ly1, lzp;
+            T lxr;
+            if (uni) {   // every face of the row is c, except possibly the two x-boundary faces (in the row constants)
+#pragma unroll
+                for (int v = 0; v < V; ++v) { lx.v[v] = c; ly0.v[v] = c; ly1.v[v] = c; lzp.v[v] = c; }
+                if (i == 1) lx.v[0] = rcur.lxf;
+                lxr = (i + V > nxi) ? rcur.lxl : c;
+            } else {
+                lx = VA::load(Lx + o); ly0 = VA::load(Ly + o); ly1 = VA::load(Ly + o + sy); lzp = VA::load(Lz + o + sz);
+                lxr = __shfl_down(lx.v[0], 1, 64);
+                if (last) lxr = Lx[o + V];
+            }
+            T left = __shfl_up(ec.v[V - 1], 1, 64), right = __shfl_down(ec.v[0], 1, 64);
+            if (first) left = src.cooks(slr);
+            if (last) right = src.cooks(srr);
+            VA ae;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const T xm = (v == 0) ? left : ec.v[v == 0 ? 0 : v - 1];
+                const T xp = (v == V - 1) ? right : ec.v[v == V - 1 ? v : v + 1];
+                const T lxlo = lx.v[v], lxhi = (v == V - 1) ? lxr : lx.v[v == V - 1 ? v : v + 1];
+                T dg = 0;
+                dg -= (lxlo + lxhi);
+                dg -= (ly0.v[v] + ly1.v[v]);
+                dg -= (lzc.v[v] + lzp.v[v]);
+                T s = ec.v[v] * dg;
+                s += xm * lxlo + xp * lxhi;
+                s += ym.v[v] * ly0.v[v] + yp.v[v] * ly1.v[v];
+                s += em.v[v] * lzc.v[v] + ep.v[v] * lzp.v[v];
+                ae.v[v] = s;
+            }
+            epi(o, ae, ec, ac, bc, acc, pre);
+            em = ec; ec = ep; epr = enr; ymr = ymn; ypr = ypn; slr = sln; srr = srn; ac = an; bc = bn; rcur = rnext; lzc = lzp;
         }
     }
     if (NRED > 0) {
@@ -162,7 +387,7 @@ __global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__r
 // Same row mapping as k_stencil7 (lane = V cells of a row, wavefront = row segment, workgroup = 4 rows marching in z).
 template <class T, int NRED, class F>
 __global__ __launch_bounds__(256) void k_rowvec(G g, F f, double *partials, int ntx, int tpp, int nblk, int clen, int klo,
-                                                int khi) {
+                                                int khi, Gate gate) {
     constexpr int V = Vec16<T>::V;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x;
@@ -173,9 +398,11 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, F f, double *partials, int 
     double acc[NRED > 0 ? NRED : 1];
 #pragma unroll
     for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) acc[q] = 0.0;
-    if (i <= g.n[0] - 2 && j <= g.n[1] - 2) {
+    Pre pre;
+    const bool run = gate_open(gate, pre);
+    if (run && i <= g.n[0] - 2 && j <= g.n[1] - 2) {
         const long col = (long)i + g.s[1] * (long)j;
-        for (int k = k0; k < k1; ++k) f(col + g.s[2] * k, j, k, acc);
+        for (int k = k0; k < k1; ++k) f(col + g.s[2] * k, j, k, acc, pre);
     }
     if (NRED > 0) {
         block_red<(NRED > 0 ? NRED : 1), 4>(acc, RED_SUM);
@@ -186,7 +413,7 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, F f, double *partials, int 
     }
 }
 template <class T, int NRED, class F>
-inline int launch_rowvec(int kclass, const G &g, F f, double *partials, int *np) {
+inline int launch_rowvec(int kclass, const G &g, F f, double *partials, int *np, Gate gate = Gate()) {
     constexpr int V = Vec16<T>::V;
     Range R = r_inside(g);
     if (np) *np = 0;
@@ -195,6 +422,7 @@ inline int launch_rowvec(int kclass, const G &g, F f, double *partials, int *np)
     const int tpp = ((ntx * nty + 7) / 8) * 8;
     const int nown = R.hi[2] - R.lo[2] + 1;
     int want = WL_MAXB / tpp;
+    if (ctx().opt[12] > 0 && ctx().opt[12] < want) want = ctx().opt[12];
     if (want < 1) want = 1;
     if (want > nown) want = nown;
     const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
@@ -203,7 +431,54 @@ inline int launch_rowvec(int kclass, const G &g, F f, double *partials, int *np)
     if (np) *np = nblk;
     Prof p(kclass, R.count());
     hipLaunchKernelGGL((k_rowvec<T, NRED, F>), dim3(nblk), dim3(256), 0, ctx().stream, g, f, partials, ntx, tpp, nblk, clen,
-                       R.lo[2], R.hi[2]);
+                       R.lo[2], R.hi[2], gate);
+    return (int)hipGetLastError();
+}
+
+// Row constants of a Poisson level (see the header comment): one wavefront scans one x-row.  c is recorded when
+//   Lx[i] == c for the interior faces i = 2..n0-2 (faces 1 and n0-1 are the domain boundary, or its periodic image),
+//   Ly[i,j] == Ly[i,j+1] == Lz[i,k] == Lz[i,k+1] == c for every interior i, and iD[i] == idc for i = 2..n0-3
+// (the two end cells have a different diagonal when the boundary faces are not c), else NaN; layout: RC_N above.
+template <class T>
+__global__ __launch_bounds__(256) void k_lrow(G g, const T *__restrict__ L, const T *__restrict__ iD, T *rowc) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nrows = (long)g.n[1] * g.n[2];
+    if (row >= nrows) return;
+    const int j = (int)(row % g.n[1]), k = (int)(row / g.n[1]);
+    const T nan = __builtin_nanf("");
+    T c = nan, idc = nan;
+    bool ok = (j >= 1 && j <= g.n[1] - 2 && k >= g.zlo && k <= g.zhi && k >= 1 && k <= g.n[2] - 2);
+    if (ok) {
+        const long base = g.at(0, j, k);
+        const T *Lx = L, *Ly = L + g.sc, *Lz = L + 2 * g.sc;
+        c = Ly[base + 1];
+        idc = iD[base + g.n[0] / 2];
+        ok = (c == c) && (idc == idc);
+        for (int i = 1 + lane; i <= g.n[0] - 2; i += 64) {
+            const long I = base + i;
+            ok = ok && Ly[I] == c && Ly[I + g.s[1]] == c && Lz[I] == c && Lz[I + g.s[2]] == c;
+            if (i >= 2) ok = ok && Lx[I] == c;
+            if (i >= 2 && i <= g.n[0] - 3) ok = ok && iD[I] == idc;
+        }
+    }
+    const unsigned long long bad = __ballot(!ok);
+    if (lane == 0) {
+        T *rc = rowc + RC_N * row;
+        rc[0] = bad ? nan : c;
+        rc[3] = idc;
+        if (!bad) {
+            const long base = g.at(0, j, k);
+            rc[1] = L[base + 1]; rc[2] = L[base + g.n[0] - 1];
+            rc[4] = iD[base + 1]; rc[5] = iD[base + g.n[0] - 2];
+        } else { rc[1] = rc[2] = rc[4] = rc[5] = nan; }
+        rc[6] = rc[7] = (T)0;
+    }
+}
+template <class T> inline int op_lrow(const G &g, const T *L, const T *iD, T *rowc) {
+    const long nrows = (long)g.n[1] * g.n[2];
+    Prof p(WL_K_MISC, g.cells());
+    hipLaunchKernelGGL((k_lrow<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ctx().stream, g, L, iD, rowc);
     return (int)hipGetLastError();
 }
 
@@ -221,7 +496,7 @@ template <class T> inline bool stencil7_ok(const G &g, const T *e, const T *L) {
 // BY = rows (wavefronts) per workgroup: 4 (256 threads) or 8 (512 threads; fewer y-halo rows re-read at tile edges),
 // selected by wl_set_option(4, .).
 template <class T, int NRED, int BY, class SRC, class EPI>
-inline int launch_stencil7_by(int kclass, const G &g, SRC src, const T *L, EPI epi, double *partials, int *np) {
+inline int launch_stencil7_by(int kclass, const G &g, SRC src, const T *L, const T *rowc, EPI epi, double *partials, int *np, Gate gate) {
     constexpr int V = Vec16<T>::V;
     Range R = r_inside(g);
     if (np) *np = 0;
@@ -231,6 +506,7 @@ inline int launch_stencil7_by(int kclass, const G &g, SRC src, const T *L, EPI e
     const int tpp = ((ntx * nty + 7) / 8) * 8;
     const int nown = khi - klo + 1;
     int want = WL_MAXB / tpp;
+    if (ctx().opt[11] > 0 && ctx().opt[11] < want) want = ctx().opt[11];
     if (want < 1) want = 1;
     if (want > nown) want = nown;
     const int clen = (nown + want - 1) / want;
@@ -239,14 +515,52 @@ inline int launch_stencil7_by(int kclass, const G &g, SRC src, const T *L, EPI e
     if (nblk > WL_MAXB) return -1;   // plane too large for the partial buffer: caller falls back
     if (np) *np = nblk;
     Prof p(kclass, R.count());
-    hipLaunchKernelGGL((k_stencil7<T, NRED, BY, SRC, EPI>), dim3(nblk), dim3(64 * BY), 0, ctx().stream, g, src, L, epi, partials,
-                       ntx, tpp, nblk, clen, klo, khi);
+    hipLaunchKernelGGL((k_stencil7<T, NRED, BY, SRC, EPI>), dim3(nblk), dim3(64 * BY), 0, ctx().stream, g, src, L, rowc, epi, partials,
+                       ntx, tpp, nblk, clen, klo, khi, gate);
+    return (int)hipGetLastError();
+}
+// Pipelined launch (wl_set_option(10, 0) falls back to the plain kernel through an adapter that loads ea/eb itself).
+template <class T, int NRED, class SRC, class EPI>
+inline int launch_stencil7p(int kclass, const G &g, SRC src, const T *L, const T *rowc, const T *ea, const T *eb, EPI epi,
+                            double *partials, int *np, Gate gate = Gate()) {
+    constexpr int V = Vec16<T>::V;
+    constexpr int BY = 4;
+    if (!ctx().opt[10]) {
+        using VA = VecA<T>;
+        return launch_stencil7_by<T, NRED, BY>(kclass, g, src, L, rowc,
+            [=] __device__(long o, const VA &ae, const VA &ec, double *acc, const Pre &pre) {
+                VA a = ec, b = ec;
+                if (ea) a = VA::load(ea + o);
+                if (eb) b = VA::load(eb + o);
+                epi(o, ae, ec, a, b, acc, pre);
+            }, partials, np, gate);
+    }
+    Range R = r_inside(g);
+    if (np) *np = 0;
+    if (R.count() <= 0) return 0;
+    const int klo = R.lo[2], khi = R.hi[2];
+    const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + BY - 1) / BY;
+    const int tpp = ((ntx * nty + 7) / 8) * 8;
+    const int nown = khi - klo + 1;
+    int want = WL_MAXB / tpp;
+    if (ctx().opt[11] > 0 && ctx().opt[11] < want) want = ctx().opt[11];
+    if (want < 1) want = 1;
+    if (want > nown) want = nown;
+    const int clen = (nown + want - 1) / want;
+    const int nchunk = (nown + clen - 1) / clen;
+    const int nblk = tpp * nchunk;
+    if (nblk > WL_MAXB) return -1;
+    if (np) *np = nblk;
+    Prof p(kclass, R.count());
+    hipLaunchKernelGGL((k_stencil7p<T, NRED, BY, SRC, EPI>), dim3(nblk), dim3(64 * BY), 0, ctx().stream, g, src, L, rowc, ea, eb, epi,
+                       partials, ntx, tpp, nblk, clen, klo, khi, gate);
     return (int)hipGetLastError();
 }
 template <class T, int NRED, class SRC, class EPI>
-inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, EPI epi, double *partials, int *np) {
-    if (ctx().opt[4]) return launch_stencil7_by<T, NRED, 8>(kclass, g, src, L, epi, partials, np);
-    return launch_stencil7_by<T, NRED, 4>(kclass, g, src, L, epi, partials, np);
+inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, const T *rowc, EPI epi, double *partials, int *np,
+                           Gate gate = Gate()) {
+    if (ctx().opt[4]) return launch_stencil7_by<T, NRED, 8>(kclass, g, src, L, rowc, epi, partials, np, gate);
+    return launch_stencil7_by<T, NRED, 4>(kclass, g, src, L, rowc, epi, partials, np, gate);
 }
 
 }  // namespace wl

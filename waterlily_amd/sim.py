@@ -502,6 +502,13 @@ def Jacobi(p, it=1, level=0):
     check(_lib.lib().wl_mg_jacobi(p._h, level, it))
 
 
+def uniform_rows(p, level=0):
+    """(rows whose face coefficients are one number, owned interior rows) of a level -- see wl_mg_uniform_rows."""
+    a, b = C.c_longlong(), C.c_longlong()
+    check(_lib.lib().wl_mg_uniform_rows(p._h, int(level), C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def set_option(key: int, value: int):
     """Tuning / A-B switches of the library (include/wlhip.h, wl_set_option)."""
     check(_lib.lib().wl_set_option(int(key), int(value)))
