@@ -27,27 +27,32 @@ os.environ.setdefault("OMP_PROC_BIND", "close")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s float4 copy)
 
-# ALGORITHMIC bytes per processed cell, in units of the element size T (each distinct array element read
-# once + written once; DESIGN.md "kernels and their algorithmic bytes").  Keyed by libwlhip kernel class.
+# ALGORITHMIC bytes per processed cell, in units of the element size T (each distinct array element the kernel's
+# operator reads once + writes once, dense -- SURVEY.md 8(d), DESIGN.md "kernels and their algorithmic bytes").
+# Keyed by libwlhip kernel class: (dense, never_moved, skipped_in_uniform_rows).  The kernels move LESS than `dense`:
+# `never_moved` is the diagonal D, recomputed from the six face coefficients; `skipped_in_uniform_rows` are the
+# coefficient arrays (L x3, iD) that are not loaded in x-rows whose coefficients are one number (rows clear of the
+# body: 94 % of the rows of the 512^3 sphere case).  roofline.achieved uses `dense` (the contract's figure, which can
+# therefore exceed the HBM peak); roofline.moved uses dense - never - phi*skipped, the bytes the kernel has to move.
 ALG_T = {
-    "conv_diff": 10.5,      # fused conv_diff!+BDIM#1: read u(3) [+u0(3) in the corrector] + V(3), write f(3): 9T/12T
-    "bdim": 22.5,           # BDIM#2: f(3) V(3) mu0(3) mu1(9) [+u(3) corrector] -> u(3): 21T/24T
-    "pcg_mult_dot": 6.0,    # eps, L(3), D -> z   (+ z.eps partial)
-    "pcg_update": 23.0 / 3, # x, eps, r, z, iD -> x, r, z  (8T; the 6th iteration skips iD/z: 6T)
-    "pcg_direction": 3.0,   # eps, z -> eps
-    "pcg_init": 4.0,        # r, iD -> z, eps
-    "smooth": 9.0,          # fused Jacobi!+increment! (the V-cycle smoother): r,iD,x,D,L(3) -> r,x = 9T (8T moved: D recomputed)
-    "jacobi": 3.0,          # r, iD -> eps
-    "increment": 9.0,       # eps, L(3), D, r, x -> r, x
-    "residual": 8.0,        # x, L(3), D, z, iD -> r
-    "restrict": 9.0,        # per COARSE cell: 8 fine reads + 1 write
-    "prolongate": 2.0,      # per fine cell: 1 write + (1/8) read, rounded up
-    "dot": 1.0,
-    "div": 4.0,
-    "correct": 10.0,        # u(3) rw, L(3), x
-    "scale": 2.0,
-    "cfl": 4.0,
-    "copy": 2.0,            # per element copied: read + write
+    "conv_diff": (10.5, 0, 0),         # fused conv_diff!+BDIM#1: u(3) [+u0(3) corrector] + V(3) -> f(3) [+u0(3) predictor]
+    "bdim": (22.5, 0, 0),              # BDIM#2: f(3) V(3) mu0(3) mu1(9) [+u(3) corrector] -> u(3): 21T/24T (dense)
+    "pcg_mult_dot": (6.0, 1, 3),       # eps, L(3), D -> z   (+ z.eps partial)
+    "pcg_update": (13.0 / 3, 0, 5.0 / 6),  # r, z, iD -> r (+ r.(r iD) partial): 4T; the 6th iteration x, eps, r, z -> x, r: 6T
+    "pcg_direction": (6.0, 0, 1),      # x, eps, r, iD -> x, eps   (x += alpha eps ; eps = beta eps + r iD)
+    "pcg_init": (3.0, 0, 1),           # r, iD -> eps
+    "smooth": (9.0, 1, 3.5),           # fused Jacobi!+increment! r,iD,x,D,L(3) -> r,x; fused prolongate!+increment! skips L only
+    "jacobi": (3.0, 0, 0),
+    "increment": (9.0, 1, 3),
+    "residual": (8.0, 1, 3),           # x, L(3), D, z, iD -> r
+    "restrict": (9.0, 0, 0),
+    "prolongate": (2.0, 0, 0),
+    "dot": (1.0, 0, 0),
+    "div": (4.0, 0, 0),
+    "correct": (10.0, 0, 0),           # u(3) rw, L(3), x
+    "scale": (2.0, 0, 0),
+    "cfl": (4.0, 0, 0),
+    "copy": (2.0, 0, 0),
 }
 
 
@@ -195,8 +200,14 @@ def main():
 
     mlups = ncell_global * args.steps / elapsed / 1e6
     avg_ms = ms.value / max(1, nl.value)
-    alg_bytes = ALG_T[dominant] * tsz * (nc.value / max(1, nl.value))
+    dense, never, skipped = ALG_T[dominant]
+    n_uni, n_rows = S.uniform_rows(sim.pois, 0)
+    phi = n_uni / max(1, n_rows)                       # share of x-rows whose L / iD loads are skipped
+    cells_per_launch = nc.value / max(1, nl.value)
+    alg_bytes = dense * tsz * cells_per_launch
+    moved_bytes = (dense - never - phi * skipped) * tsz * cells_per_launch
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    moved_rate = moved_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
@@ -216,6 +227,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": nl.value,
                      "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "moved": {"bytes_per_launch": moved_bytes, "GB/s": moved_rate, "frac": moved_rate / HBM_PEAK_GBS,
+                               "uniform_row_fraction": phi,
+                               "note": "achieved/frac use the dense algorithmic bytes of SURVEY 8(d); the kernel skips the "
+                                       "loads of L/iD in coefficient-uniform rows and recomputes D, so it moves only "
+                                       "`moved.bytes_per_launch` (compare `traffic`, the PMC-measured bytes)"},
                      "per_class_ms_one_step": per_class},
     }
     if not args.no_cpu_baseline and world == 1:

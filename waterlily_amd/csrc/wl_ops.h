@@ -490,15 +490,41 @@ _Pragma("unroll")
 
 // a .*= s  /  a ./= s over the whole scalar array (src/Flow.jl:139,144).  `dbl`: the scalar is Float64
 // (w = 0.5 makes dt = w*dt a Float64, :138) so the operation is done in Float64 and rounded.
+// The array is one contiguous span [a, a + n_last*s_last) of the caller's allocation (ghosts and, in a padded layout,
+// the row padding included -- padding is never read by anything), so this is a flat 16-B-vector streaming kernel.
+template <class T>
+__global__ __launch_bounds__(256) void k_scale_flat(T *a, long n, long head, double s, T sT, bool divide, bool dbl) {
+    constexpr int V = 16 / sizeof(T);
+    auto one = [&](T x) -> T {
+        if (dbl) return divide ? (T)((double)x / s) : (T)((double)x * s);
+        return divide ? x / sT : x * sT;
+    };
+    const long nv = (n - head) / V;                 // whole aligned vectors after the unaligned head
+    const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
+    for (long q = t0; q < nv; q += nt) {
+        VecA<T> v = VecA<T>::load(a + head + q * V);
+#pragma unroll
+        for (int e = 0; e < V; ++e) v.v[e] = one(v.v[e]);
+        v.store(a + head + q * V);
+    }
+    if (t0 < head) a[t0] = one(a[t0]);              // unaligned head (< V elements)
+    const long tail = head + nv * V + t0;           // and tail
+    if (t0 < V && tail < n) a[tail] = one(a[tail]);
+}
 template <class T, int D>
 int op_scale_all(const G &g, T *a, double s, bool divide, bool dbl) {
-    const G gg = g;
-    const T sT = (T)s;
-    return launch_range(WL_K_SCALE, r_whole(g), [=] __device__(int i, int j, int k) {
-        T *p = a + gg.at(i, j, k);
-        if (dbl) *p = divide ? (T)((double)*p / s) : (T)((double)*p * s);
-        else *p = divide ? *p / sT : *p * sT;
-    });
+    constexpr int V = 16 / sizeof(T);
+    const long n = span(g);
+    const long mis = (long)((reinterpret_cast<uintptr_t>(a) & 15) / sizeof(T));
+    long head = mis ? V - mis : 0;
+    if (head > n) head = n;
+    const long nv = (n - head) / V;
+    long nb = (nv + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+    Prof p(WL_K_SCALE, r_whole(g).count());
+    hipLaunchKernelGGL((k_scale_flat<T>), dim3((unsigned)nb), dim3(256), 0, ctx().stream, a, n, head, s, (T)s, divide, dbl);
+    return (int)hipGetLastError();
 }
 
 // @inside z[I] = div(I,u)  src/Flow.jl:11-17,139
@@ -646,7 +672,7 @@ int op_residual(const LevelT<T> &p, int permask, double *partials, State *st) {
     if constexpr (D == 3) {
         if (stencil7_ok<T>(p.g, p.x, p.L) && stencil7_ok<T>(p.g, p.r, p.iD) && stencil7_ok<T>(p.g, p.z, p.L)) {
             using VA = VecA<T>;
-            rcv = launch_stencil7p<T, 1>(WL_K_RESIDUAL, p.g, SrcArray<T>{p.x}, p.L, p.rowc, p.iD, p.z,
+            rcv = launch_stencil7ab<T, 1>(WL_K_RESIDUAL, p.g, SrcArray<T>{p.x}, p.L, p.rowc, p.iD, p.z,
                 [=] __device__(long o, const VA &ax, const VA &, const VA &id, const VA &zz, double *acc, const Pre &) {
                 VA rv;
 _Pragma("unroll")
@@ -688,7 +714,7 @@ int op_increment(const LevelT<T> &p, int permask) {
     if constexpr (D == 3) {
         if (stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.r, p.x)) {
             using VA = VecA<T>;
-            const int rcv = launch_stencil7p<T, 0>(WL_K_INCREMENT, p.g, SrcArray<T>{p.eps}, p.L, p.rowc, p.r, p.x,
+            const int rcv = launch_stencil7ab<T, 0>(WL_K_INCREMENT, p.g, SrcArray<T>{p.eps}, p.L, p.rowc, p.r, p.x,
                 [=] __device__(long o, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
                 VA rv = r0, xv = x0;
 _Pragma("unroll")
@@ -732,7 +758,7 @@ int op_smooth_fused(const LevelT<T> &p, T *rout) {
     if constexpr (D == 3) {
         if (stencil7_ok<T>(p.g, p.r, p.L) && stencil7_ok<T>(p.g, p.iD, p.x) && stencil7_ok<T>(p.g, rout, p.L)) {
             using VA = VecA<T>;
-            const int rcv = launch_stencil7p<T, 0>(WL_K_SMOOTH, p.g, SrcJacobi<T>{p.r, p.iD, p.rowc, p.g.n[0], p.g.n[1]}, p.L, p.rowc,
+            const int rcv = launch_stencil7ab<T, 0>(WL_K_SMOOTH, p.g, SrcJacobi<T>{p.r, p.iD, p.rowc, p.g.n[0], p.g.n[1]}, p.L, p.rowc,
                 p.r, p.x, [=] __device__(long o, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
                     VA rv = r0, xv = x0;
 _Pragma("unroll")
@@ -774,7 +800,7 @@ int op_prolong_increment_fused(const LevelT<T> &p, const T *rin, const G &gc, co
         if (stencil7_ok<T>(p.g, p.r, p.L) && stencil7_ok<T>(p.g, rin, p.x)) {
             using VA = VecA<T>;
             const SrcProlong<T> src{cx, C, p.g.n[0], p.g.n[1], p.g.nzg, p.g.kz0};
-            const int rcv = launch_stencil7p<T, 0>(WL_K_SMOOTH, p.g, src, p.L, p.rowc, rin, p.x,
+            const int rcv = launch_stencil7ab<T, 0>(WL_K_SMOOTH, p.g, src, p.L, p.rowc, rin, p.x,
                 [=] __device__(long o, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
                     VA rv = r0, xv = x0;
 _Pragma("unroll")
@@ -890,7 +916,7 @@ _Pragma("unroll")
                     if (rcv == 0) { T *tmp = ecur; ecur = eoth; eoth = tmp; }
                 } else {
                 const T *esrc = ecur;
-                rcv = launch_stencil7p<T, 1>(WL_K_PCG_MULT, p.g, SrcArray<T>{esrc}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
+                rcv = launch_stencil7ab<T, 1>(WL_K_PCG_MULT, p.g, SrcArray<T>{esrc}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
                     [=] __device__(long o, const VA &ae, const VA &ec, const VA &, const VA &, double *acc, const Pre &) {
                     ae.store(q.z + o);
 _Pragma("unroll")

@@ -50,13 +50,6 @@ template <class T> struct SrcArray {          // e is an array (pcg!: eps, resid
     const T *e;
     __device__ __forceinline__ VecA<T> vec(long o, int, int, int) const { return VecA<T>::load(e + o); }
     __device__ __forceinline__ T scal(long o, int, int, int) const { return e[o]; }
-    // split form for the software-pipelined kernel: raw() only issues loads, cook() does the arithmetic (if any)
-    using Raw = VecA<T>;
-    using RawS = T;
-    __device__ __forceinline__ Raw raw(long o, int, int, int) const { return VecA<T>::load(e + o); }
-    __device__ __forceinline__ VecA<T> cook(const Raw &r) const { return r; }
-    __device__ __forceinline__ RawS raws(long o, int, int, int) const { return e[o]; }
-    __device__ __forceinline__ T cooks(const RawS &r) const { return r; }
 };
 // iD of the V cells at (i..i+V-1, j, k): the row constant where the row is coefficient-uniform (k_lrow; the two end
 // cells of a row are excluded from that guarantee, so the vectors holding them are loaded), else the array.
@@ -108,19 +101,6 @@ template <class T> struct SrcJacobi {         // e = r*iD evaluated on the fly (
         return c;
     }
     __device__ __forceinline__ T scal(long o, int, int, int) const { return r[o] * iD[o]; }
-    struct Raw { VecA<T> a, b; };
-    struct RawS { T a, b; };
-    __device__ __forceinline__ Raw raw(long o, int i, int j, int k) const {
-        return Raw{VecA<T>::load(r + o), load_iD<T>(iD, rowc, n0, n1, o, i, j, k)};
-    }
-    __device__ __forceinline__ VecA<T> cook(const Raw &q) const {
-        VecA<T> c;
-#pragma unroll
-        for (int v = 0; v < VecA<T>::V; ++v) c.v[v] = q.a.v[v] * q.b.v[v];
-        return c;
-    }
-    __device__ __forceinline__ RawS raws(long o, int, int, int) const { return RawS{r[o], iD[o]}; }
-    __device__ __forceinline__ T cooks(const RawS &q) const { return q.a * q.b; }
 };
 template <class T> struct SrcDirection {      // e = beta*eps + r*iD : pcg!'s new search direction on the fly (Poisson.jl:136,140)
     const T *e, *r, *iD;
@@ -157,12 +137,6 @@ template <class T> struct SrcProlong {        // e[I] = coarse x[down(I)] inside
         for (int v = 0; v < VecA<T>::V; v += 2) { const T p = row[(i + v + 1) / 2]; c.v[v] = p; c.v[v + 1] = p; }
         return c;
     }
-    using Raw = VecA<T>;
-    using RawS = T;
-    __device__ __forceinline__ Raw raw(long o, int i, int j, int k) const { return vec(o, i, j, k); }
-    __device__ __forceinline__ VecA<T> cook(const Raw &r) const { return r; }
-    __device__ __forceinline__ RawS raws(long o, int i, int j, int k) const { return scal(o, i, j, k); }
-    __device__ __forceinline__ T cooks(const RawS &r) const { return r; }
 };
 
 // Device-side gate and scalars of a solver kernel, read ONCE per thread before its z loop (uniform addresses): inside
@@ -216,28 +190,32 @@ __global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__r
         const int ju = __builtin_amdgcn_readfirstlane(j);   // a wavefront works on ONE row: row constants are scalar loads
         const T *rcp = rowc ? rowc + RC_N * ((long)ju + (long)g.n[1] * k0) : nullptr;
         const long rcs = RC_N * (long)g.n[1];
-        T cn = rcp ? rcp[0] : (T)0;
+        RowC<T> rn;
+        rn.c = rn.lxf = rn.lxl = rn.idc = (T)0;
+        if (rcp) rn = load_rowc<T>(rcp);
         for (int k = k0; k < k1; ++k) {
             const long o = col + sz * k;
-            const T c = cn;
+            const RowC<T> rc = rn;
+            const T c = rc.c;
             const bool uni = rcp && (c == c);
-            if (rcp) { rcp += rcs; cn = rcp[0]; }           // next plane's row constant (plane k1 <= n2-1 exists)
+            if (rcp) { rcp += rcs; rn = load_rowc<T>(rcp); }   // next plane's row constants (plane k1 <= n2-1 exists)
             const VA ym = src.vec(o - sy, i, j - 1, k), yp = src.vec(o + sy, i, j + 1, k);
             VA lx, ly0, ly1, lzp;
             T lxr;
-            if (uni) {   // all faces of this row are c, except possibly the two x-boundary faces (read by the end lanes)
+            if (uni) {   // all faces of this row are c, except possibly the two x-boundary faces (in the row constants)
 #pragma unroll
                 for (int v = 0; v < V; ++v) { lx.v[v] = c; ly0.v[v] = c; ly1.v[v] = c; lzp.v[v] = c; }
-                if (i == 1) lx.v[0] = Lx[o];
-                lxr = c;
+                if (i == 1) lx.v[0] = rc.lxf;
+                lxr = (i + V > nxi) ? rc.lxl : c;
             } else {
                 lx = VA::load(Lx + o); ly0 = VA::load(Ly + o); ly1 = VA::load(Ly + o + sy); lzp = VA::load(Lz + o + sz);
                 lxr = __shfl_down(lx.v[0], 1, 64);
+                if (last) lxr = Lx[o + V];
             }
             // x neighbours of the vector ends: adjacent lane, or memory at the two ends of the row segment
             T left = __shfl_up(ec.v[V - 1], 1, 64), right = __shfl_down(ec.v[0], 1, 64);
             if (first) left = src.scal(o - 1, i - 1, j, k);
-            if (last) { right = src.scal(o + V, i + V, j, k); lxr = Lx[o + V]; }
+            if (last) right = src.scal(o + V, i + V, j, k);
             // issued last: nothing in this iteration waits for it (plane k1 is the last one that exists for this chunk)
             const int kn = (k + 2 <= k1) ? k + 2 : k1;
             const VA en = src.vec(col + sz * kn, i, j, kn);
@@ -259,119 +237,6 @@ __global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__r
             }
             epi(o, ae, ec, acc, pre);
             em = ec; ec = ep; ep = en; lzc = lzp;
-        }
-    }
-    if (NRED > 0) {
-        block_red<(NRED > 0 ? NRED : 1), BY>(acc, RED_SUM);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int q = 0; q < NRED; ++q) partials[(long)q * gridDim.x + blockIdx.x] = acc[q];
-        }
-    }
-}
-
-// ---- software-pipelined form of k_stencil7 (the default).  Same arithmetic; what changes is WHEN loads are issued.
-// In the plain kernel every plane's loads are consumed in the iteration that issues them, so each wavefront sits
-// out one memory latency per plane and the achieved rate is (occupancy x bytes per plane) / latency, well under the
-// HBM rate once L is skipped.  Here iteration k only ISSUES the loads of later planes -- e at k+2, the rows j-1/j+1,
-// the edge scalars, the row constants and the two epilogue operands (ea, eb: e.g. r and x of increment!) at k+1 --
-// and consumes values requested one iteration earlier.  Sources expose raw() (loads only) and cook() (arithmetic)
-// so that e.g. r*iD of the Jacobi source is formed when the operands are used, not when they are requested.
-// EPI(o, Ae, e, a, b, acc, pre): a, b = the V values of ea, eb at o (undefined when the pointer is null).
-template <class T, int NRED, int BY, class SRC, class EPI>
-__global__ __launch_bounds__(64 * BY) void k_stencil7p(G g, SRC src, const T *__restrict__ L, const T *__restrict__ rowc,
-                                                   const T *ea, const T *eb, EPI epi, double *partials, int ntx, int tpp,
-                                                   int nblk, int clen, int klo, int khi, Gate gate) {
-    constexpr int V = Vec16<T>::V;
-    using VA = VecA<T>;
-    using Raw = typename SRC::Raw;
-    using RawS = typename SRC::RawS;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int b = blockIdx.x;
-    const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);   // XCD-contiguous logical id
-    const int ch = lb / tpp, pt = lb - ch * tpp;
-    const int nxi = g.n[0] - 2, nyi = g.n[1] - 2;
-    const int i = 1 + (pt % ntx) * 64 * V + lane * V;
-    const int j = 1 + (pt / ntx) * BY + wv;
-    const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);
-    double acc[NRED > 0 ? NRED : 1];
-#pragma unroll
-    for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) acc[q] = 0.0;
-    Pre pre;
-    const bool run = gate_open(gate, pre);
-    const bool active = run && (i <= nxi) && (j <= nyi) && (k0 < k1);
-    if (active) {
-        const bool first = (lane == 0), last = (lane == 63) || (i + V > nxi);
-        const long sy = g.s[1], sz = g.s[2], sc = g.sc;
-        const long col = (long)i + sy * (long)j;
-        const T *Lx = L, *Ly = L + sc, *Lz = L + 2 * sc;
-        const long o0 = col + sz * k0;
-        VA em = src.cook(src.raw(o0 - sz, i, j, k0 - 1)), ec = src.cook(src.raw(o0, i, j, k0));
-        Raw epr = src.raw(o0 + sz, i, j, k0 + 1);
-        Raw ymr = src.raw(o0 - sy, i, j - 1, k0), ypr = src.raw(o0 + sy, i, j + 1, k0);
-        RawS slr = src.raws(first ? o0 - 1 : o0, first ? i - 1 : i, j, k0);   // only the end lanes use theirs
-        RawS srr = src.raws(last ? o0 + V : o0, last ? i + V : i, j, k0);
-        VA ac = em, bc = em;
-        if (ea) ac = VA::load(ea + o0);
-        if (eb) bc = VA::load(eb + o0);
-        VA lzc = VA::load(Lz + o0);
-        const int ju = __builtin_amdgcn_readfirstlane(j);
-        const T *rcp = rowc ? rowc + RC_N * ((long)ju + (long)g.n[1] * k0) : nullptr;
-        const long rcs = RC_N * (long)g.n[1];
-        RowC<T> rcur;
-        rcur.c = rcur.lxf = rcur.lxl = rcur.idc = (T)0;
-        if (rcp) rcur = load_rowc<T>(rcp);
-        for (int k = k0; k < k1; ++k) {
-            const long o = col + sz * k;
-            // ---- requests (consumed in the next iteration; planes k+1 <= k1 and rows j-1, j+1 always exist)
-            const Raw ymn = src.raw(o + sz - sy, i, j - 1, k + 1), ypn = src.raw(o + sz + sy, i, j + 1, k + 1);
-            VA an = ac, bn = bc;
-            if (ea) an = VA::load(ea + o + sz);
-            if (eb) bn = VA::load(eb + o + sz);
-            RowC<T> rnext = rcur;
-            if (rcp) { rcp += rcs; rnext = load_rowc<T>(rcp); }
-            RawS sln = slr, srn = srr;
-            if (first) sln = src.raws(o + sz - 1, i - 1, j, k + 1);
-            if (last) srn = src.raws(o + sz + V, i + V, j, k + 1);
-            const int kn = (k + 2 <= k1) ? k + 2 : k1;   // plane k1 is the last one this chunk may touch
-            const Raw enr = src.raw(col + sz * kn, i, j, kn);
-            // ---- this plane
-            const VA ep = src.cook(epr), ym = src.cook(ymr), yp = src.cook(ypr);
-            const T c = rcur.c;
-            const bool uni = rowc && (c == c);
-            VA lx, ly0, ly1, lzp;
-            T lxr;
-            if (uni) {   // every face of the row is c, except possibly the two x-boundary faces (in the row constants)
-#pragma unroll
-                for (int v = 0; v < V; ++v) { lx.v[v] = c; ly0.v[v] = c; ly1.v[v] = c; lzp.v[v] = c; }
-                if (i == 1) lx.v[0] = rcur.lxf;
-                lxr = (i + V > nxi) ? rcur.lxl : c;
-            } else {
-                lx = VA::load(Lx + o); ly0 = VA::load(Ly + o); ly1 = VA::load(Ly + o + sy); lzp = VA::load(Lz + o + sz);
-                lxr = __shfl_down(lx.v[0], 1, 64);
-                if (last) lxr = Lx[o + V];
-            }
-            T left = __shfl_up(ec.v[V - 1], 1, 64), right = __shfl_down(ec.v[0], 1, 64);
-            if (first) left = src.cooks(slr);
-            if (last) right = src.cooks(srr);
-            VA ae;
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const T xm = (v == 0) ? left : ec.v[v == 0 ? 0 : v - 1];
-                const T xp = (v == V - 1) ? right : ec.v[v == V - 1 ? v : v + 1];
-                const T lxlo = lx.v[v], lxhi = (v == V - 1) ? lxr : lx.v[v == V - 1 ? v : v + 1];
-                T dg = 0;
-                dg -= (lxlo + lxhi);
-                dg -= (ly0.v[v] + ly1.v[v]);
-                dg -= (lzc.v[v] + lzp.v[v]);
-                T s = ec.v[v] * dg;
-                s += xm * lxlo + xp * lxhi;
-                s += ym.v[v] * ly0.v[v] + yp.v[v] * ly1.v[v];
-                s += em.v[v] * lzc.v[v] + ep.v[v] * lzp.v[v];
-                ae.v[v] = s;
-            }
-            epi(o, ae, ec, ac, bc, acc, pre);
-            em = ec; ec = ep; epr = enr; ymr = ymn; ypr = ypn; slr = sln; srr = srn; ac = an; bc = bn; rcur = rnext; lzc = lzp;
         }
     }
     if (NRED > 0) {
@@ -519,48 +384,27 @@ inline int launch_stencil7_by(int kclass, const G &g, SRC src, const T *L, const
                        ntx, tpp, nblk, clen, klo, khi, gate);
     return (int)hipGetLastError();
 }
-// Pipelined launch (wl_set_option(10, 0) falls back to the plain kernel through an adapter that loads ea/eb itself).
-template <class T, int NRED, class SRC, class EPI>
-inline int launch_stencil7p(int kclass, const G &g, SRC src, const T *L, const T *rowc, const T *ea, const T *eb, EPI epi,
-                            double *partials, int *np, Gate gate = Gate()) {
-    constexpr int V = Vec16<T>::V;
-    constexpr int BY = 4;
-    if (!ctx().opt[10]) {
-        using VA = VecA<T>;
-        return launch_stencil7_by<T, NRED, BY>(kclass, g, src, L, rowc,
-            [=] __device__(long o, const VA &ae, const VA &ec, double *acc, const Pre &pre) {
-                VA a = ec, b = ec;
-                if (ea) a = VA::load(ea + o);
-                if (eb) b = VA::load(eb + o);
-                epi(o, ae, ec, a, b, acc, pre);
-            }, partials, np, gate);
-    }
-    Range R = r_inside(g);
-    if (np) *np = 0;
-    if (R.count() <= 0) return 0;
-    const int klo = R.lo[2], khi = R.hi[2];
-    const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + BY - 1) / BY;
-    const int tpp = ((ntx * nty + 7) / 8) * 8;
-    const int nown = khi - klo + 1;
-    int want = WL_MAXB / tpp;
-    if (ctx().opt[11] > 0 && ctx().opt[11] < want) want = ctx().opt[11];
-    if (want < 1) want = 1;
-    if (want > nown) want = nown;
-    const int clen = (nown + want - 1) / want;
-    const int nchunk = (nown + clen - 1) / clen;
-    const int nblk = tpp * nchunk;
-    if (nblk > WL_MAXB) return -1;
-    if (np) *np = nblk;
-    Prof p(kclass, R.count());
-    hipLaunchKernelGGL((k_stencil7p<T, NRED, BY, SRC, EPI>), dim3(nblk), dim3(64 * BY), 0, ctx().stream, g, src, L, rowc, ea, eb, epi,
-                       partials, ntx, tpp, nblk, clen, klo, khi, gate);
-    return (int)hipGetLastError();
-}
 template <class T, int NRED, class SRC, class EPI>
 inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, const T *rowc, EPI epi, double *partials, int *np,
                            Gate gate = Gate()) {
     if (ctx().opt[4]) return launch_stencil7_by<T, NRED, 8>(kclass, g, src, L, rowc, epi, partials, np, gate);
     return launch_stencil7_by<T, NRED, 4>(kclass, g, src, L, rowc, epi, partials, np, gate);
+}
+// Launch with two epilogue operand arrays: EPI(o, Ae, e, a, b, acc, pre) receives the V values of ea and eb at o
+// (e.g. r and x of increment!), loaded next to the stencil operands.  (A software-pipelined variant of the kernel --
+// loads of plane k+1/k+2 issued one iteration ahead, sources split into load/arithmetic halves -- was measured at
+// 512^3 and 256^3: no gain, 124-152 VGPRs; the kernels are not latency-bound.  See DESIGN.md.)
+template <class T, int NRED, class SRC, class EPI>
+inline int launch_stencil7ab(int kclass, const G &g, SRC src, const T *L, const T *rowc, const T *ea, const T *eb, EPI epi,
+                             double *partials, int *np, Gate gate = Gate()) {
+    using VA = VecA<T>;
+    return launch_stencil7<T, NRED>(kclass, g, src, L, rowc,
+        [=] __device__(long o, const VA &ae, const VA &ec, double *acc, const Pre &pre) {
+            VA a = ec, b = ec;
+            if (ea) a = VA::load(ea + o);
+            if (eb) b = VA::load(eb + o);
+            epi(o, ae, ec, a, b, acc, pre);
+        }, partials, np, gate);
 }
 
 }  // namespace wl
