@@ -17,6 +17,8 @@
 // The arithmetic per flux and the order of the six +/- updates per cell are exactly those of the reference
 // (and of the generic gather kernel in wl_ops.h), so results are bit-identical to the oracle.
 #pragma once
+#include <type_traits>
+
 #include "wl_common.h"
 
 namespace wl {
@@ -29,8 +31,12 @@ constexpr int CD_HALO = CD_W * CD_R - CD_BX * CD_BY;  // 288 halo cells per comp
 // flux through one face (src/Flow.jl:6,8,9 + the diffusive term of :45,:54,:55), returned in Float64:
 //   interior face : phiu  - nu*d      lower boundary: phiuL - nu*d      upper boundary: phiuR - nu*d
 // fm2,fm1,f0,fp1 = f[I-2s], f[I-s], f[I], f[I+s] of the transported component, uf = face velocity.
-template <class T>
+// GEN = false: the caller knows that no face of this workgroup's tile is a domain-boundary face in this plane
+// (lowbnd = topbnd = bnd = false everywhere): the compiler drops the central-flux and Float64-accumulation variants
+// instead of evaluating them next to the interior ones and selecting (about a third of the VALU work of a cell).
+template <class T, bool GEN = true>
 __device__ __forceinline__ double cd_flux(T fm2, T fm1, T f0, T fp1, double uf, T nu, bool lowbnd, bool topbnd) {
+    if (!GEN) { lowbnd = false; topbnd = false; }
     const bool neg = uf < 0;
     const bool up = topbnd ? !neg : (uf > 0);      // phiuR takes the upwind-from-below triple unless u<0
     const T q = quick<T>(up ? fm2 : fp1, up ? fm1 : f0, up ? f0 : fm1);
@@ -40,10 +46,12 @@ __device__ __forceinline__ double cd_flux(T fm2, T fm1, T f0, T fp1, double uf, 
     const T nud = nu * (T)(f0 - fm1);
     return flux - (double)nud;
 }
-template <class T> __device__ __forceinline__ T cd_add(T r, double F, bool bnd) {   // r += flux (lower face)
+template <class T, bool GEN = true> __device__ __forceinline__ T cd_add(T r, double F, bool bnd) {   // r += flux (lower face)
+    if (!GEN) return r + (T)F;
     return bnd ? (T)((double)r + F) : r + (T)F;
 }
-template <class T> __device__ __forceinline__ T cd_sub(T r, double F, bool bnd) {   // r -= flux (upper face)
+template <class T, bool GEN = true> __device__ __forceinline__ T cd_sub(T r, double F, bool bnd) {   // r -= flux (upper face)
+    if (!GEN) return r - (T)F;
     return bnd ? (T)((double)r - F) : r - (T)F;
 }
 
@@ -137,42 +145,49 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
         const bool zlb = !ring && (kg == 1), ztb = !ring && (kg == nzg - 1);
         T rr[3] = {0, 0, 0};
         double Fz[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const T *P = SM(s1, c) + own_l;  // plane k, component c, centred on the own cell
-            // ---- z: lower face of cell k (also the upper face of the carried cell k-1)
-            double ufz;
-            if (c == 0) ufz = (double)((T)(W[2][2] + SM(s1, 2)[own_l - 1]) * (T)0.5);
-            else if (c == 1) ufz = (double)((T)(W[2][2] + SM(s1, 2)[own_l - CD_W]) * (T)0.5);
-            else ufz = (double)((T)(W[2][2] + W[2][1]) * (T)0.5);
-            Fz[c] = cd_flux<T>(W[c][0], W[c][1], W[c][2], W[c][3], ufz, nu, zlb, ztb);
-            if (own && lowok) {
-                // ---- x: lower face i, upper face i+1
-                const T xm2 = P[-2], xm1 = P[-1], x0 = W[c][2], xp1 = P[1], xp2 = P[2];
-                double ufl, ufu;
-                const T *PX = SM(s1, 0) + own_l;
-                if (c == 0) { ufl = (double)((T)(PX[0] + PX[-1]) * (T)0.5); ufu = (double)((T)(PX[1] + PX[0]) * (T)0.5); }
-                else if (c == 1) { ufl = (double)((T)(PX[0] + PX[-CD_W]) * (T)0.5); ufu = (double)((T)(PX[1] + PX[1 - CD_W]) * (T)0.5); }
-                else { ufl = (double)((T)(PX[0] + W[0][1]) * (T)0.5); ufu = (double)((T)(PX[1] + SM(s0, 0)[own_l + 1]) * (T)0.5); }
-                const bool xlb = (i == 1), xtb = (i == n0 - 2);
-                rr[c] = cd_add<T>(rr[c], cd_flux<T>(xm2, xm1, x0, xp1, ufl, nu, xlb, false), xlb);
-                rr[c] = cd_sub<T>(rr[c], cd_flux<T>(xm1, x0, xp1, xp2, ufu, nu, false, xtb), xtb);
-                // ---- y: lower face j, upper face j+1   (only rows j <= n1-2 take part, util.jl:55-57)
-                if (j <= n1 - 2) {
-                    const T ym2 = P[-2 * CD_W], ym1 = P[-CD_W], yp1 = P[CD_W], yp2 = P[2 * CD_W];
-                    const T *PY = SM(s1, 1) + own_l;
-                    double vfl, vfu;
-                    if (c == 0) { vfl = (double)((T)(PY[0] + PY[-1]) * (T)0.5); vfu = (double)((T)(PY[CD_W] + PY[CD_W - 1]) * (T)0.5); }
-                    else if (c == 1) { vfl = (double)((T)(PY[0] + PY[-CD_W]) * (T)0.5); vfu = (double)((T)(PY[CD_W] + PY[0]) * (T)0.5); }
-                    else { vfl = (double)((T)(PY[0] + W[1][1]) * (T)0.5); vfu = (double)((T)(PY[CD_W] + SM(s0, 1)[own_l + CD_W]) * (T)0.5); }
-                    const bool ylb = (j == 1), ytb = (j == n1 - 2);
-                    rr[c] = cd_add<T>(rr[c], cd_flux<T>(ym2, ym1, x0, yp1, vfl, nu, ylb, false), ylb);
-                    rr[c] = cd_sub<T>(rr[c], cd_flux<T>(ym1, x0, yp1, yp2, vfu, nu, false, ytb), ytb);
+        // boundary faces of this tile in this plane? (x: first / last tile of a row; y: the tiles holding j = 1 and
+        // j = n1-2; z: the planes kg = 1 and kg = nzg-1) -- uniform over the workgroup
+        const bool bface = (i0 == 1) || (i0 + CD_BX > n0 - 2) || (j0 <= 1) || (j0 + CD_BY > n1 - 2) || zlb || ztb;
+        auto fluxes = [&](auto gen) {
+            constexpr bool GEN = decltype(gen)::value;
+    #pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const T *P = SM(s1, c) + own_l;  // plane k, component c, centred on the own cell
+                // ---- z: lower face of cell k (also the upper face of the carried cell k-1)
+                double ufz;
+                if (c == 0) ufz = (double)((T)(W[2][2] + SM(s1, 2)[own_l - 1]) * (T)0.5);
+                else if (c == 1) ufz = (double)((T)(W[2][2] + SM(s1, 2)[own_l - CD_W]) * (T)0.5);
+                else ufz = (double)((T)(W[2][2] + W[2][1]) * (T)0.5);
+                Fz[c] = cd_flux<T, GEN>(W[c][0], W[c][1], W[c][2], W[c][3], ufz, nu, zlb, ztb);
+                if (own && lowok) {
+                    // ---- x: lower face i, upper face i+1
+                    const T xm2 = P[-2], xm1 = P[-1], x0 = W[c][2], xp1 = P[1], xp2 = P[2];
+                    double ufl, ufu;
+                    const T *PX = SM(s1, 0) + own_l;
+                    if (c == 0) { ufl = (double)((T)(PX[0] + PX[-1]) * (T)0.5); ufu = (double)((T)(PX[1] + PX[0]) * (T)0.5); }
+                    else if (c == 1) { ufl = (double)((T)(PX[0] + PX[-CD_W]) * (T)0.5); ufu = (double)((T)(PX[1] + PX[1 - CD_W]) * (T)0.5); }
+                    else { ufl = (double)((T)(PX[0] + W[0][1]) * (T)0.5); ufu = (double)((T)(PX[1] + SM(s0, 0)[own_l + 1]) * (T)0.5); }
+                    const bool xlb = (i == 1), xtb = (i == n0 - 2);
+                    rr[c] = cd_add<T, GEN>(rr[c], cd_flux<T, GEN>(xm2, xm1, x0, xp1, ufl, nu, xlb, false), xlb);
+                    rr[c] = cd_sub<T, GEN>(rr[c], cd_flux<T, GEN>(xm1, x0, xp1, xp2, ufu, nu, false, xtb), xtb);
+                    // ---- y: lower face j, upper face j+1   (only rows j <= n1-2 take part, util.jl:55-57)
+                    if (j <= n1 - 2) {
+                        const T ym2 = P[-2 * CD_W], ym1 = P[-CD_W], yp1 = P[CD_W], yp2 = P[2 * CD_W];
+                        const T *PY = SM(s1, 1) + own_l;
+                        double vfl, vfu;
+                        if (c == 0) { vfl = (double)((T)(PY[0] + PY[-1]) * (T)0.5); vfu = (double)((T)(PY[CD_W] + PY[CD_W - 1]) * (T)0.5); }
+                        else if (c == 1) { vfl = (double)((T)(PY[0] + PY[-CD_W]) * (T)0.5); vfu = (double)((T)(PY[CD_W] + PY[0]) * (T)0.5); }
+                        else { vfl = (double)((T)(PY[0] + W[1][1]) * (T)0.5); vfu = (double)((T)(PY[CD_W] + SM(s0, 1)[own_l + CD_W]) * (T)0.5); }
+                        const bool ylb = (j == 1), ytb = (j == n1 - 2);
+                        rr[c] = cd_add<T, GEN>(rr[c], cd_flux<T, GEN>(ym2, ym1, x0, yp1, vfl, nu, ylb, false), ylb);
+                        rr[c] = cd_sub<T, GEN>(rr[c], cd_flux<T, GEN>(ym1, x0, yp1, yp2, vfu, nu, false, ytb), ytb);
+                    }
+                    // ---- z lower face of the own cell (cells k <= n2-2 take part in z)
+                    if (ring || kg <= nzg - 2) rr[c] = cd_add<T, GEN>(rr[c], Fz[c], zlb);
                 }
-                // ---- z lower face of the own cell (cells k <= n2-2 take part in z)
-                if (ring || kg <= nzg - 2) rr[c] = cd_add<T>(rr[c], Fz[c], zlb);
             }
-        }
+        };
+        if (bface) fluxes(std::true_type{}); else fluxes(std::false_type{});
         // ---- C. finish and store: the carried cell k-1 gets its upper z flux; cell k is stored now when it
         //         takes no upper z flux (k == 0, k == n2-1, or j == 0), else it is carried
         auto emit = [&](int kk, const T(&val)[3], const T(&q0)[3], const T(&qV)[3]) {
