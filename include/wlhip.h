@@ -232,7 +232,9 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  * key 8: 1 = pcg! applies x += alpha*eps in the direction kernel instead of the update kernel (default; one array
  *        pass less per iteration, identical values), 0 = in the update kernel as the reference orders it
  * key 9: 1 = the 7-point kernels skip the loads of L in rows whose face coefficients are all one number (rows clear
- *        of the body and the domain faces; constants recorded by wl_mg_update) (default), 0 = always load L */
+ *        of the body and the domain faces; constants recorded by wl_mg_update) (default), 0 = always load L
+ * key 13: 1 = pcg! does not store z' = r*iD, the direction kernel recomputes it (default), 0 = stored as in the reference
+ * keys 11, 12: > 0 = cap on the number of z-chunks of the 7-point / streaming vector kernels (measurement only) */
 int wl_set_option(int key, int value);
 
 /* ------------------------------------------------------------------ measurement support */

@@ -334,7 +334,7 @@ template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double d
     WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u)));
     WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
     WL_TRY((mg_solve<T, D>(b, 1e-4, 32, n_iter)));
-    WL_TRY((op_correct<T, D>(g, (T *)a->d.u, p.L, p.x)));
+    WL_TRY((op_correct<T, D>(g, (T *)a->d.u, p.L, p.x, p.rowc)));
     return op_scale_all<T, D>(g, p.x, dts, true, dbl);
 }
 

@@ -540,10 +540,11 @@ _Pragma("unroll")
     });
 }
 
-// 16-B vectorised form of the velocity correction for D=3 (same layout requirements as wl_stencil7.h)
+// 16-B vectorised form of the velocity correction for D=3 (same layout requirements as wl_stencil7.h).
+// rowc (optional): row constants of L (wl_stencil7.h): in a coefficient-uniform row L is not loaded.
 template <class T>
 __global__ __launch_bounds__(64 * S7_BY) void k_correct3(G g, T *__restrict__ u, const T *__restrict__ L, const T *__restrict__ x,
-                                                  int ntx, int tpp, int nblk, int clen, int klo, int khi) {
+                                                  const T *__restrict__ rowc, int ntx, int tpp, int nblk, int clen, int klo, int khi) {
     constexpr int V = Vec16<T>::V;
     using VA = VecA<T>;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -556,13 +557,25 @@ __global__ __launch_bounds__(64 * S7_BY) void k_correct3(G g, T *__restrict__ u,
     const long sy = g.s[1], sz = g.s[2], sc = g.sc;
     const long col = (long)i + sy * (long)j;
     VA xm = VA::load(x + col + sz * (k0 - 1));
+    const int ju = __builtin_amdgcn_readfirstlane(j);
+    const T *rcp = rowc ? rowc + RC_N * ((long)ju + (long)g.n[1] * k0) : nullptr;
     for (int k = k0; k < k1; ++k) {
         const long o = col + sz * k;
         const VA xc = VA::load(x + o), xy = VA::load(x + o - sy);
         T left = __shfl_up(xc.v[V - 1], 1, 64);
         if (lane == 0) left = x[o - 1];
         VA u0 = VA::load(u + o), u1 = VA::load(u + o + sc), u2 = VA::load(u + o + 2 * sc);
-        const VA l0 = VA::load(L + o), l1 = VA::load(L + o + sc), l2 = VA::load(L + o + 2 * sc);
+        VA l0, l1, l2;
+        RowC<T> rc;
+        rc.c = rc.lxf = rc.lxl = rc.idc = (T)0;
+        if (rcp) { rc = load_rowc<T>(rcp); rcp += RC_N * (long)g.n[1]; }
+        if (rowc && rc.c == rc.c) {   // the lower faces of the row are all c, except the x-boundary face of cell 1
+#pragma unroll
+            for (int v = 0; v < V; ++v) { l0.v[v] = rc.c; l1.v[v] = rc.c; l2.v[v] = rc.c; }
+            if (i == 1) l0.v[0] = rc.lxf;
+        } else {
+            l0 = VA::load(L + o); l1 = VA::load(L + o + sc); l2 = VA::load(L + o + 2 * sc);
+        }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             const T xl = (v == 0) ? left : xc.v[v == 0 ? 0 : v - 1];
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(64 * S7_BY) void k_correct3(G g, T *__restrict__ u,
 
 // u[I,i] -= L[I,i]*d_i x  src/Flow.jl:141-143 (three loops fused: they touch disjoint components)
 template <class T, int D>
-int op_correct(const G &g, T *u, const T *L, const T *x) {
+int op_correct(const G &g, T *u, const T *L, const T *x, const T *rowc = nullptr) {
     if constexpr (D == 3) {
         if (stencil7_ok<T>(g, u, L) && stencil7_ok<T>(g, x, L)) {
             constexpr int V = Vec16<T>::V;
@@ -591,7 +604,7 @@ int op_correct(const G &g, T *u, const T *L, const T *x) {
             if (want > nown) want = nown;
             const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
             Prof p(WL_K_CORRECT, R.count());
-            hipLaunchKernelGGL((k_correct3<T>), dim3(tpp * nchunk), dim3(64 * S7_BY), 0, ctx().stream, g, u, L, x, ntx, tpp,
+            hipLaunchKernelGGL((k_correct3<T>), dim3(tpp * nchunk), dim3(64 * S7_BY), 0, ctx().stream, g, u, L, x, rowc, ntx, tpp,
                                tpp * nchunk, clen, R.lo[2], R.hi[2]);
             return (int)hipGetLastError();
         }
