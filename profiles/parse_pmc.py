@@ -39,6 +39,8 @@ def classify(name):
         return "conv_diff"
     if "k_correct3" in name:
         return "correct"
+    if "k_scale_flat" in name:
+        return "scale"
     if "k_rowvec" in name:
         m = re.search(r"(op_\w+?)<", name)
         o = re.search(r"#(\d)\}", name)
