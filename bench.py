@@ -56,7 +56,7 @@ ALG_T = {
 }
 
 
-def sphere(dims, T, Re=3700.0, device="cuda:0"):
+def sphere(dims, T, Re=3700.0, device="cuda:0", padded=True):
     """reference README.md:118-125: radius=m/8, center=m/2-1, L=2radius, nu=U*L/Re (m = shortest side; the
     sphere sits at the same x,y position and in the middle of the z extent)"""
     import torch
@@ -66,7 +66,8 @@ def sphere(dims, T, Re=3700.0, device="cuda:0"):
     radius = m / 8
     cx, cy, cz = m / 2 - 1, dims[1] / 2 - 1, dims[2] / 2 - 1
     body = AutoBody(lambda x, t: torch.sqrt((x[0] - cx) ** 2 + (x[1] - cy) ** 2 + (x[2] - cz) ** 2) - radius)
-    return S.Simulation(tuple(dims), (1.0, 0.0, 0.0), 2 * radius, nu=2 * radius / Re, body=body, T=T, device=device)
+    return S.Simulation(tuple(dims), (1.0, 0.0, 0.0), 2 * radius, nu=2 * radius / Re, body=body, T=T, device=device,
+                        padded=padded)
 
 
 def cpu_baseline(size: int, steps: int):
@@ -112,6 +113,8 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=192)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layout", default="padded", choices=["padded", "dense"],
+                    help="padded: rows 128-B aligned (default); dense: the reference's column-major layout (pitch N+2)")
     ap.add_argument("--kernel", default=None, help="force the kernel class reported in `roofline`")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "host"],
                     help="multi-rank transport: rccl (one GPU per rank) or host (gloo staging; lets ranks share a GPU, tests)")
@@ -150,7 +153,7 @@ def main():
     # global grid is 512 x 512 x 512N; --grid gives an explicit global grid instead (strong scaling).
     dims = tuple(args.grid) if args.grid else (m, m, m * world)
     scaling = "strong" if args.grid else "weak"
-    sim = sphere(dims, T, device=dev)
+    sim = sphere(dims, T, device=dev, padded=(args.layout == "padded"))
     ncell_global = int(np.prod(dims))
     ncell = ncell_global // world            # cells per rank: threshold for "finest level" launches
     names = class_table(L)
@@ -220,7 +223,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"3D sphere {dims[0]}x{dims[1]}x{dims[2]}, Re=3700, {args.dtype}, uniform inflow, "
-                               f"remeasure=false" + (" (BASELINE configs[2])" if world == 1 and not args.grid and m == 512
+                               f"remeasure=false" + (", dense layout" if args.layout == "dense" else "") + (" (BASELINE configs[2])" if world == 1 and not args.grid and m == 512
                                                      and args.dtype == "f32" else "" if world == 1 else
                                                      f", z-slabs over {world} GPUs (RCCL halo exchange)"),
                    "vcycles_per_solve": vcycles[:6], "mean_vcycles_per_step": float(np.sum(vcycles)) / args.steps},

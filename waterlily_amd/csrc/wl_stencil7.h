@@ -1,8 +1,8 @@
 // wl_stencil7.h -- the 7-point variable-coefficient operator  A e = D e + sum_d L[I,d] e[I-d] + L[I+d,d] e[I+d]
 // (src/Poisson.jl:69-75) for D=3 as a 16-byte-vectorised z-marching kernel.
 //
-//   * one lane owns V = 16/sizeof(T) consecutive x cells (float4 / double2): every global access is an aligned
-//     16-B vector -> 1 KiB per wave instruction, the coalescing sweet spot of gfx950;
+//   * one lane owns V = 16/sizeof(T) consecutive x cells (float4 / double2): every global access is a 16-B vector
+//     -> 1 KiB per wave instruction, the coalescing sweet spot of gfx950 (16-B aligned in the padded layout);
 //   * a wavefront spans 64*V cells of one row; a 256-thread workgroup = 4 rows; the workgroup marches along z
 //     with a 3-deep register window of e (k-1,k,k+1) and a 2-deep window of L_z, so e and L_z are loaded ONCE
 //     per cell; x neighbours come from the adjacent lane (wave shuffle) -- only the two edge lanes of a row
@@ -16,16 +16,20 @@
 //   * an epilogue functor turns A e into the operator at hand: z=Ae & z.e (pcg!), r-=Ae & x+=e (increment!),
 //     r = z-Ax (residual!), with per-thread Float64 partials reduced exactly like the range kernels.
 // Per-cell arithmetic and its order are those of mult()/set_diag! => bit-identical to the generic kernels.
-// Requirements (else the caller falls back to the generic range kernel): D==3, (n0-2) % V == 0 and every row's
-// first interior element 16-B aligned (true for the padded layout of the Python host).
+// Requirements (else the caller falls back to the generic range kernel): D==3 and (n0-2) % V == 0.
 #pragma once
 #include "wl_common.h"
 
 namespace wl {
 
+// 16-byte vectors with ELEMENT alignment: the compiler still emits one global_load/store_dwordx4 per access (gfx950
+// runs with unaligned global access enabled), so rows of the reference's dense layout (pitch N+2, not 16-B aligned)
+// take the same kernels as the padded layout; a misaligned wave access merely touches one more 128-B line.
+typedef float wl_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double wl_d2u __attribute__((ext_vector_type(2), aligned(8)));
 template <class T> struct Vec16;
-template <> struct Vec16<float> { static constexpr int V = 4; using type = float4; };
-template <> struct Vec16<double> { static constexpr int V = 2; using type = double2; };
+template <> struct Vec16<float> { static constexpr int V = 4; using type = wl_f4u; };
+template <> struct Vec16<double> { static constexpr int V = 2; using type = wl_d2u; };
 
 template <class T> struct VecA {   // array view of a 16-B vector
     static constexpr int V = Vec16<T>::V;
@@ -347,14 +351,13 @@ template <class T> inline int op_lrow(const G &g, const T *L, const T *iD, T *ro
     return (int)hipGetLastError();
 }
 
-// can the vector kernel run on this level?
+// can the vector kernel run on this level?  (e, L: the arrays involved -- kept for call-site symmetry; any element-
+// aligned pointer and any strides will do)
 template <class T> inline bool stencil7_ok(const G &g, const T *e, const T *L) {
     constexpr int V = Vec16<T>::V;
+    (void)e; (void)L;
     if (!ctx().opt[0]) return false;
-    if (g.D != 3 || (g.n[0] - 2) % V != 0 || g.n[0] - 2 < V) return false;
-    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return al(e + 1) && al(L + 1) && (g.s[1] * sizeof(T)) % 16 == 0 && (g.s[2] * sizeof(T)) % 16 == 0 &&
-           (g.sc * sizeof(T)) % 16 == 0;
+    return g.D == 3 && (g.n[0] - 2) % V == 0 && g.n[0] - 2 >= V;
 }
 
 // launch over the owned interior planes; *np = number of partials per reduced value (0 if nothing to do).
