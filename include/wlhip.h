@@ -252,6 +252,8 @@ int wl_prof_select(int kclass, int64_t min_cells);
 int wl_prof_reset(void);
 /* launches / cells processed per class since the last reset (all classes, all levels) */
 int wl_prof_counts(int kclass, int64_t *launches, int64_t *cells);
+/* number of stencil launches since start-up that were split to overlap a z-slab halo exchange (comm stream) */
+int wl_prof_overlapped(int64_t *count);
 /* for the selected class: timed launches, their summed cells, summed milliseconds (synchronises) */
 int wl_prof_timed(int64_t *launches, int64_t *cells, double *ms);
 

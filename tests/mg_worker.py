@@ -13,6 +13,9 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C  # noqa: E402
+
+from waterlily_amd import _lib  # noqa: E402
 from waterlily_amd import dist as wd  # noqa: E402
 from waterlily_amd import sim as S  # noqa: E402
 from waterlily_amd.body import AutoBody, norm2  # noqa: E402
@@ -71,6 +74,9 @@ def main():
             # f), a ring of slabs has no such planes (gather() fills them by wrapping): compare the interior planes
             a, b = a[:, :, 1:-1], b[:, :, 1:-1]
         out["d_" + k] = float(np.max(np.abs(a - b)) / max(1e-30, np.max(np.abs(b))))
+    nov = C.c_int64()
+    _lib.check(_lib.lib().wl_prof_overlapped(C.byref(nov)))
+    out["overlapped"] = int(nov.value)
     out["force_ref"] = S.pressure_force(ref).tolist()
     out["force_slab"] = S.pressure_force(sim).tolist()
     wd.finalize()

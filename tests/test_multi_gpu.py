@@ -25,8 +25,8 @@ def free_port():
     return p
 
 
-def run_workers(script, nproc, *args, timeout=600):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+def run_workers(script, nproc, *args, timeout=600, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", script), *args]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
@@ -89,6 +89,17 @@ def test_slabs_match_undecomposed(nproc, case):
     # z-periodic cases ("zper") run on a RING of slabs (rank 0 <-> rank P-1 exchange)
     nslab = sum(1 for _, d in out["levels"] if d)
     assert (nslab >= 3 if "deep" in case else nslab == 1) and not out["levels"][-1][1]
+    assert out["overlapped"] > 0          # stencil launches were split around exchanges on the comm stream
+    check(out, "f64" if case.endswith("f64") else "f32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,case", [(2, "sphere_deep_f32"), (4, "sphere_long_zper_deep_f64")])
+def test_slabs_match_without_overlap(nproc, case):
+    """Same, with the halo exchanges issued in-stream (WL_OVERLAP=0) instead of on the comm stream with the stencil
+    launches split into inner planes (concurrent with the transfer) and the two boundary planes (after it)."""
+    out = run_workers("mg_worker.py", nproc, case, WL_OVERLAP="0")
+    assert out["overlapped"] == 0
     check(out, "f64" if case.endswith("f64") else "f32")
 
 

@@ -132,6 +132,7 @@ def lib() -> C.CDLL:
         "wl_kernel_name": (C.c_char_p, [i]),
         "wl_prof_select": (i, [i, i64]),
         "wl_prof_reset": (i, []),
+        "wl_prof_overlapped": (i, [C.POINTER(i64)]),
         "wl_prof_counts": (i, [i, C.POINTER(i64), C.POINTER(i64)]),
         "wl_prof_timed": (i, [C.POINTER(i64), C.POINTER(i64), dp]),
     }

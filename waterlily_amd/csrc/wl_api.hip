@@ -998,6 +998,11 @@ int wl_prof_counts(int kclass, int64_t *launches, int64_t *cells) {
     *cells = ctx().cells[kclass];
     return 0;
 }
+int wl_prof_overlapped(int64_t *count) {
+    if (!count) return fail(WL_E_ARG, "wl_prof_overlapped: null output", __FILE__, __LINE__);
+    *count = ctx().n_overlapped;
+    return 0;
+}
 int wl_prof_timed(int64_t *launches, int64_t *cells, double *ms) {
     Ctx &c = ctx();
     WL_HIP(hipStreamSynchronize(c.stream));

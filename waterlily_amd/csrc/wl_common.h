@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include <cstdlib>
+
 #include "../../include/wlhip.h"
 
 namespace wl {
@@ -49,6 +51,12 @@ struct Ctx {
     int64_t prof_min_cells = 0;
     std::vector<TimedEvt> evts;
     std::vector<hipEvent_t> pool;
+    // halo exchange overlapped with interior compute (halo_begin / halo_end)
+    int overlap = -1;                  // -1: read WL_OVERLAP on first use (default on), 0 off, 1 on
+    hipStream_t cstream = nullptr;     // non-blocking comm stream (does not synchronise with the null stream)
+    hipEvent_t ev_prod = nullptr, ev_halo = nullptr;
+    bool halo_pending = false;
+    int64_t n_overlapped = 0;          // stencil launches split around an exchange (wl_prof_overlapped)
 };
 Ctx &ctx();
 int fail(int code, const char *what, const char *file, int line);
@@ -371,6 +379,48 @@ template <class T> inline int halo_exchange(const G &g, T *a, int ncomp, int dep
         if (rc) { (void)cm->group_end(); return rc; }
     }
     return cm->group_end();
+}
+
+// ---- overlapped form: halo_begin enqueues the exchange on the comm stream (after everything enqueued so far on the
+// compute stream), halo_end makes the compute stream wait for it.  Kernels launched in between run concurrently with
+// the transfer and must neither read the halo planes of `a` nor write its outermost owned planes.  The comm stream
+// is non-blocking, so the two streams are ordered by these two events only.  Every RCCL call of the process is still
+// totally ordered (exchange -> halo_end -> later all-reduces on the compute stream -> next halo_begin): the
+// communicator never sees two operations in flight.  WL_OVERLAP=0 in the environment restores in-stream exchanges.
+inline bool overlap_on() {
+    Ctx &c = ctx();
+    if (c.overlap < 0) {
+        const char *e = getenv("WL_OVERLAP");
+        c.overlap = (e && e[0] == '0') ? 0 : 1;
+    }
+    return c.overlap == 1 && c.comm && c.comm->size > 1;
+}
+template <class T> inline int halo_begin(const G &g, T *a, int ncomp, int depth) {
+    Ctx &c = ctx();
+    if (!g.dist || !c.comm || c.comm->size == 1) return 0;
+    if (!overlap_on()) return halo_exchange<T>(g, a, ncomp, depth);
+    if (!c.cstream) {
+        WL_HIP(hipStreamCreateWithFlags(&c.cstream, hipStreamNonBlocking));
+        WL_HIP(hipEventCreateWithFlags(&c.ev_prod, hipEventDisableTiming));
+        WL_HIP(hipEventCreateWithFlags(&c.ev_halo, hipEventDisableTiming));
+    }
+    WL_HIP(hipEventRecord(c.ev_prod, c.stream));
+    WL_HIP(hipStreamWaitEvent(c.cstream, c.ev_prod, 0));
+    hipStream_t compute = c.stream;
+    c.stream = c.cstream;                       // the transport enqueues on ctx().stream
+    const int rc = halo_exchange<T>(g, a, ncomp, depth);
+    c.stream = compute;
+    if (rc) return rc;
+    WL_HIP(hipEventRecord(c.ev_halo, c.cstream));
+    c.halo_pending = true;
+    return 0;
+}
+inline int halo_end() {
+    Ctx &c = ctx();
+    if (!c.halo_pending) return 0;
+    c.halo_pending = false;
+    WL_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------ device math

@@ -145,8 +145,9 @@ int op_bc_vec_fused(const G &g, T *a, const double *A, int saveexit, int permask
 }
 
 // perBC!(a,perdir)  src/util.jl:227-231
+// exchange = false: only the x/y copies; the caller exchanges the z halos itself (launch_stencil7_halo overlaps it)
 template <class T, int D>
-int op_bc_per(const G &g, T *a, int permask) {
+int op_bc_per(const G &g, T *a, int permask, bool exchange = true) {
     for (int j = 0; j < D; ++j)
         if ((permask >> j) & 1) {
             if (j == 2 && g.dist) {
@@ -162,7 +163,7 @@ int op_bc_per(const G &g, T *a, int permask) {
         }
     // z-slab decomposition: the reference calls perBC! exactly where a stencil operand's ghosts must be current
     // (mult!, residual!, increment!, pcg!, end of solver!), which is also where the z halos must be exchanged
-    return halo_exchange<T>(g, a, 1, 1);
+    return exchange ? halo_exchange<T>(g, a, 1, 1) : 0;
 }
 
 // exitBC!(u,u0,U,dt)  src/util.jl:216-222
@@ -678,14 +679,16 @@ int op_mult(const LevelT<T> &p, T *x, int permask) {
 // residual!  src/Poisson.jl:91-97
 template <class T, int D>
 int op_residual(const LevelT<T> &p, int permask, double *partials, State *st) {
-    WL_TRY((op_bc_per<T, D>(p.g, p.x, permask)));
+    WL_TRY((op_bc_per<T, D>(p.g, p.x, permask, false)));
     const LevelT<T> q = p;
     int np = 0;
     int rcv = -1;
+    bool exchanged = false;
     if constexpr (D == 3) {
         if (stencil7_ok<T>(p.g, p.x, p.L) && stencil7_ok<T>(p.g, p.r, p.iD) && stencil7_ok<T>(p.g, p.z, p.L)) {
             using VA = VecA<T>;
-            rcv = launch_stencil7ab<T, 1>(WL_K_RESIDUAL, p.g, SrcArray<T>{p.x}, p.L, p.rowc, p.iD, p.z,
+            exchanged = true;
+            rcv = launch_stencil7_halo<T, 1>(WL_K_RESIDUAL, p.g, p.x, SrcArray<T>{p.x}, p.L, p.rowc, p.iD, p.z,
                 [=] __device__(long o, const VA &ax, const VA &, const VA &id, const VA &zz, double *acc, const Pre &) {
                 VA rv;
 _Pragma("unroll")
@@ -698,6 +701,7 @@ _Pragma("unroll")
             if (rcv > 0) return rcv;
         }
     }
+    if (!exchanged) WL_TRY((halo_exchange<T>(p.g, p.x, 1, 1)));
     if (rcv != 0)
     WL_TRY((launch_range_red<1>(WL_K_RESIDUAL, r_inside(p.g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
         const long I = q.g.at(i, j, k);
@@ -722,12 +726,14 @@ _Pragma("unroll")
 // increment!  src/Poisson.jl:99-103
 template <class T, int D>
 int op_increment(const LevelT<T> &p, int permask) {
-    WL_TRY((op_bc_per<T, D>(p.g, p.eps, permask)));
+    WL_TRY((op_bc_per<T, D>(p.g, p.eps, permask, false)));
     const LevelT<T> q = p;
+    bool exchanged = false;
     if constexpr (D == 3) {
         if (stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.r, p.x)) {
             using VA = VecA<T>;
-            const int rcv = launch_stencil7ab<T, 0>(WL_K_INCREMENT, p.g, SrcArray<T>{p.eps}, p.L, p.rowc, p.r, p.x,
+            exchanged = true;
+            const int rcv = launch_stencil7_halo<T, 0>(WL_K_INCREMENT, p.g, p.eps, SrcArray<T>{p.eps}, p.L, p.rowc, p.r, p.x,
                 [=] __device__(long o, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
                 VA rv = r0, xv = x0;
 _Pragma("unroll")
@@ -738,6 +744,7 @@ _Pragma("unroll")
             if (rcv >= 0) return rcv;
         }
     }
+    if (!exchanged) WL_TRY((halo_exchange<T>(p.g, p.eps, 1, 1)));
     return launch_range(WL_K_INCREMENT, r_inside(p.g), [=] __device__(int i, int j, int k) {
         const long I = q.g.at(i, j, k);
         q.r[I] = q.r[I] - mult1r<T, D>(q.g, q.L, q.eps, I);
@@ -766,12 +773,14 @@ int op_jacobi(const LevelT<T> &p, int it, int permask) {
 // read the old r: no race, eps is never written.  Same per-cell operations => same bits as the two-pass form.
 template <class T, int D>
 int op_smooth_fused(const LevelT<T> &p, T *rout) {
-    WL_TRY((halo_exchange<T>(p.g, p.r, 1, 1)));   // z-slab runs: eps at halo cells = r*iD of the neighbour rank
+    // z-slab runs: eps at halo cells = r*iD of the neighbour rank, so r is exchanged (overlapped with the inner planes)
     const LevelT<T> q = p;
+    bool exchanged = false;
     if constexpr (D == 3) {
         if (stencil7_ok<T>(p.g, p.r, p.L) && stencil7_ok<T>(p.g, p.iD, p.x) && stencil7_ok<T>(p.g, rout, p.L)) {
             using VA = VecA<T>;
-            const int rcv = launch_stencil7ab<T, 0>(WL_K_SMOOTH, p.g, SrcJacobi<T>{p.r, p.iD, p.rowc, p.g.n[0], p.g.n[1]}, p.L, p.rowc,
+            exchanged = true;
+            const int rcv = launch_stencil7_halo<T, 0>(WL_K_SMOOTH, p.g, p.r, SrcJacobi<T>{p.r, p.iD, p.rowc, p.g.n[0], p.g.n[1]}, p.L, p.rowc,
                 p.r, p.x, [=] __device__(long o, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
                     VA rv = r0, xv = x0;
 _Pragma("unroll")
@@ -782,6 +791,7 @@ _Pragma("unroll")
             if (rcv >= 0) return rcv;
         }
     }
+    if (!exchanged) WL_TRY((halo_exchange<T>(p.g, p.r, 1, 1)));
     return launch_range(WL_K_SMOOTH, r_inside(p.g), [=] __device__(int i, int j, int k) {
         const long I = q.g.at(i, j, k);
         T lo[D], hi[D];
@@ -910,13 +920,14 @@ _Pragma("unroll")
         st->active = !((rho < 0 ? -rho : rho) < eps10);
     })));
     for (int n = 1; n <= it; ++n) {
-        WL_TRY((op_bc_per<T, D>(p.g, p.eps, permask)));  // :129 (no-op unless periodic)
+        WL_TRY((op_bc_per<T, D>(p.g, p.eps, permask, false)));  // :129 (x/y copies; the z-slab halo exchange follows)
+        bool exchanged = false;
         // :130-131
         int rcv = -1;
         if constexpr (D == 3) {
             if (stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.z, p.L)) {
                 using VA = VecA<T>;
-                if (fusedir && n > 1) {
+                if (fusedir && n > 1) {   // (never on a decomposed level: no exchange needed)
                     // :140 of the previous iteration + :130-131: eps_new = beta*eps + r*iD (out of place), z = A eps_new
                     T *eo = eoth;
                     rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g, SrcDirection<T>{ecur, p.r, p.iD, &st->beta}, p.L, p.rowc,
@@ -929,7 +940,8 @@ _Pragma("unroll")
                     if (rcv == 0) { T *tmp = ecur; ecur = eoth; eoth = tmp; }
                 } else {
                 const T *esrc = ecur;
-                rcv = launch_stencil7ab<T, 1>(WL_K_PCG_MULT, p.g, SrcArray<T>{esrc}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
+                exchanged = true;
+                rcv = launch_stencil7_halo<T, 1>(WL_K_PCG_MULT, p.g, ecur, SrcArray<T>{esrc}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
                     [=] __device__(long o, const VA &ae, const VA &ec, const VA &, const VA &, double *acc, const Pre &) {
                     ae.store(q.z + o);
 _Pragma("unroll")
@@ -939,6 +951,7 @@ _Pragma("unroll")
                 if (rcv > 0) return rcv;
             }
         }
+        if (!exchanged) WL_TRY((halo_exchange<T>(p.g, p.eps, 1, 1)));
         if (rcv != 0)
         WL_TRY((launch_range_red<1>(WL_K_PCG_MULT, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
             if (!st->active) return;

@@ -364,10 +364,12 @@ template <class T> inline bool stencil7_ok(const G &g, const T *e, const T *L) {
 // BY = rows (wavefronts) per workgroup: 4 (256 threads) or 8 (512 threads; fewer y-halo rows re-read at tile edges),
 // selected by wl_set_option(4, .).
 template <class T, int NRED, int BY, class SRC, class EPI>
-inline int launch_stencil7_by(int kclass, const G &g, SRC src, const T *L, const T *rowc, EPI epi, double *partials, int *np, Gate gate) {
+inline int launch_stencil7_by(int kclass, const G &g, SRC src, const T *L, const T *rowc, EPI epi, double *partials, int *np, Gate gate,
+                              int kov_lo = 0, int kov_hi = -1) {
     constexpr int V = Vec16<T>::V;
     Range R = r_inside(g);
     if (np) *np = 0;
+    if (kov_hi >= kov_lo) { R.lo[2] = kov_lo > R.lo[2] ? kov_lo : R.lo[2]; R.hi[2] = kov_hi < R.hi[2] ? kov_hi : R.hi[2]; }   // plane sub-range
     if (R.count() <= 0) return 0;
     const int klo = R.lo[2], khi = R.hi[2];
     const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + BY - 1) / BY;
@@ -389,9 +391,9 @@ inline int launch_stencil7_by(int kclass, const G &g, SRC src, const T *L, const
 }
 template <class T, int NRED, class SRC, class EPI>
 inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, const T *rowc, EPI epi, double *partials, int *np,
-                           Gate gate = Gate()) {
-    if (ctx().opt[4]) return launch_stencil7_by<T, NRED, 8>(kclass, g, src, L, rowc, epi, partials, np, gate);
-    return launch_stencil7_by<T, NRED, 4>(kclass, g, src, L, rowc, epi, partials, np, gate);
+                           Gate gate = Gate(), int kov_lo = 0, int kov_hi = -1) {
+    if (ctx().opt[4]) return launch_stencil7_by<T, NRED, 8>(kclass, g, src, L, rowc, epi, partials, np, gate, kov_lo, kov_hi);
+    return launch_stencil7_by<T, NRED, 4>(kclass, g, src, L, rowc, epi, partials, np, gate, kov_lo, kov_hi);
 }
 // Launch with two epilogue operand arrays: EPI(o, Ae, e, a, b, acc, pre) receives the V values of ea and eb at o
 // (e.g. r and x of increment!), loaded next to the stencil operands.  (A software-pipelined variant of the kernel --
@@ -399,7 +401,7 @@ inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, const T 
 // 512^3 and 256^3: no gain, 124-152 VGPRs; the kernels are not latency-bound.  See DESIGN.md.)
 template <class T, int NRED, class SRC, class EPI>
 inline int launch_stencil7ab(int kclass, const G &g, SRC src, const T *L, const T *rowc, const T *ea, const T *eb, EPI epi,
-                             double *partials, int *np, Gate gate = Gate()) {
+                             double *partials, int *np, Gate gate = Gate(), int kov_lo = 0, int kov_hi = -1) {
     using VA = VecA<T>;
     return launch_stencil7<T, NRED>(kclass, g, src, L, rowc,
         [=] __device__(long o, const VA &ae, const VA &ec, double *acc, const Pre &pre) {
@@ -407,7 +409,37 @@ inline int launch_stencil7ab(int kclass, const G &g, SRC src, const T *L, const 
             if (ea) a = VA::load(ea + o);
             if (eb) b = VA::load(eb + o);
             epi(o, ae, ec, a, b, acc, pre);
-        }, partials, np, gate);
+        }, partials, np, gate, kov_lo, kov_hi);
+}
+
+// The same launch on a z-slab level whose operand `hal` (one halo plane per side) has to be exchanged first
+// (where the reference calls perBC! on the operand).  With a comm stream available (halo_begin) the planes that do
+// not read a halo plane are computed WHILE the exchange is in flight; the first and last owned plane follow once it
+// has landed.  Reduction partials of the three launches are laid end to end (NRED <= 1).  Not decomposed / overlap
+// off / fewer than 3 planes: exchange in-stream, one launch.
+template <class T, int NRED, class SRC, class EPI>
+inline int launch_stencil7_halo(int kclass, const G &g, T *hal, SRC src, const T *L, const T *rowc, const T *ea, const T *eb,
+                                EPI epi, double *partials, int *np, Gate gate = Gate()) {
+    static_assert(NRED <= 1, "partials of the split launches are concatenated: one reduced value at most");
+    const Range R = r_inside(g);
+    const int lo = R.lo[2], hi = R.hi[2];
+    if (!g.dist || !overlap_on() || hi - lo + 1 < 3) {
+        WL_TRY((halo_exchange<T>(g, hal, 1, 1)));
+        return launch_stencil7ab<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials, np, gate);
+    }
+    WL_TRY((halo_begin<T>(g, hal, 1, 1)));
+    ctx().n_overlapped += 1;
+    int n1 = 0, n2 = 0, n3 = 0;
+    int rc = launch_stencil7ab<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials, &n1, gate, lo + 1, hi - 1);
+    const int rce = halo_end();
+    if (rc) return rc;      // (-1: not applicable -- the exchange has been waited for, the caller's fallback may run)
+    if (rce) return rce;
+    rc = launch_stencil7ab<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials ? partials + n1 : nullptr, &n2, gate, lo, lo);
+    if (rc) return rc > 0 ? rc : fail(WL_E_STATE, "split 7-point launch: boundary plane rejected", __FILE__, __LINE__);
+    rc = launch_stencil7ab<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials ? partials + n1 + n2 : nullptr, &n3, gate, hi, hi);
+    if (rc) return rc > 0 ? rc : fail(WL_E_STATE, "split 7-point launch: boundary plane rejected", __FILE__, __LINE__);
+    if (np) *np = n1 + n2 + n3;
+    return 0;
 }
 
 }  // namespace wl
