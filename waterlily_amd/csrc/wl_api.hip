@@ -351,18 +351,15 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     // u0 and f); scale_u!(a,0) is folded into the predictor BDIM #2 (MODE 1).
     // (z-slab runs: u carries a 2-plane halo for QUICK, f a 1-plane halo for mu_ddn; exchanges are no-ops otherwise)
     WL_TRY((op_conv_diff<T, D, true, true>(g, f, u, d.nu, d.perdir_mask, nullptr, V, dt, gp, gp != nullptr, u0)));
-    WL_TRY((halo_exchange<T>(g, f, D, 1)));
-    WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy)));
+    WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true)));   // + exchange of f (overlapped)
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, u, u0, U, dt, a->sc.partials, a->sc.st)));
     WL_TRY((halo_exchange<T>(g, u, D, 1)));
     WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0])));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
-    WL_TRY((halo_exchange<T>(g, u, D, 2)));
-    // corrector (:164-167)
-    WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr)));
-    WL_TRY((halo_exchange<T>(g, f, D, 1)));
-    WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy)));
+    // corrector (:164-167); the 2-plane exchange of u is issued inside op_conv_diff (overlapped with its inner planes)
+    WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr, nullptr, true)));
+    WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     WL_TRY((halo_exchange<T>(g, u, D, 1)));
     WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1])));

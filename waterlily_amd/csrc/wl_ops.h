@@ -290,12 +290,28 @@ _Pragma("unroll")
 // dispatch: D=3 non-periodic -> LDS-tiled marching kernel (wl_convdiff.h) + generic gather on the two x-ghost
 // planes; everything else (2-D, periodic directions) -> generic gather kernel over the whole array.
 // COPY: also perform `u0 .= u` (Flow.jl:154) for the cells written (u0out), the epilogue then uses u itself.
+// exchange_u (z-slab runs): the 2-plane halo exchange of u that has to precede this call is issued HERE, on the comm
+// stream, and the LDS kernel runs on the planes that read no halo plane (zlo+2 .. zhi-2) while it is in flight.
 template <class T, int D, bool FUSE, bool COPY = false>
 int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T *u0, const T *V, double dt_,
-                 const double *acc, bool has_acc, T *u0out = nullptr) {
+                 const double *acc, bool has_acc, T *u0out = nullptr, bool exchange_u = false) {
     if constexpr (D == 3) {
         if (ctx().opt[2] && (permask == 0 || (permask == 4 && g.zring)) && g.n[0] >= 5 && g.n[1] >= 5 && g.n[2] >= 5) {
-            WL_TRY((launch_convdiff3<T, FUSE, COPY>(g, r, u, nu_, u0, u0out, V, dt_, acc, has_acc)));
+            if (exchange_u && g.dist && overlap_on() && g.zhi - g.zlo + 1 >= 5) {
+                WL_TRY((halo_begin<T>(g, const_cast<T *>(u), D, 2)));
+                G gi = g;
+                gi.zlo = g.zlo + 2; gi.zhi = g.zhi - 2;
+                const int rc = launch_convdiff3<T, FUSE, COPY>(gi, r, u, nu_, u0, u0out, V, dt_, acc, has_acc);
+                WL_TRY(halo_end());
+                if (rc) return rc;
+                G gl = g, gh = g;
+                gl.zhi = g.zlo + 1; gh.zlo = g.zhi - 1;
+                WL_TRY((launch_convdiff3<T, FUSE, COPY>(gl, r, u, nu_, u0, u0out, V, dt_, acc, has_acc)));
+                WL_TRY((launch_convdiff3<T, FUSE, COPY>(gh, r, u, nu_, u0, u0out, V, dt_, acc, has_acc)));
+            } else {
+                if (exchange_u) WL_TRY((halo_exchange<T>(g, const_cast<T *>(u), D, 2)));
+                WL_TRY((launch_convdiff3<T, FUSE, COPY>(g, r, u, nu_, u0, u0out, V, dt_, acc, has_acc)));
+            }
             Range R0 = r_whole(g), R1 = r_whole(g);
             R0.hi[0] = 0;
             R1.lo[0] = g.n[0] - 1;
@@ -303,6 +319,7 @@ int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T 
             return op_conv_diff_range<T, D, FUSE, COPY>(g, R1, r, u, nu_, permask, u0, V, dt_, acc, has_acc, u0out);
         }
     }
+    if (exchange_u) WL_TRY((halo_exchange<T>(g, const_cast<T *>(u), D, 2)));
     return op_conv_diff_range<T, D, FUSE, COPY>(g, r_whole(g), r, u, nu_, permask, u0, V, dt_, acc, has_acc, u0out);
 }
 
@@ -367,11 +384,14 @@ __global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *f, const
 
 // `rowfree` (optional, mom_step! only): rowfree[j + n1*k] != 0 means mu1 == 0, V == 0 and mu0 == 1 on x-row (j,k), so
 // the statement reduces to u (+)= f -- same value, 15 coefficient reads and 6 neighbour reads per cell skipped.
+// exchange_f (z-slab runs): the 1-plane halo exchange of f that mu_ddn needs is issued HERE on the comm stream; the pass
+// over the body-free rows (which reads no neighbour of f) runs while it is in flight, the busy rows after it.
 template <class T, int D, int MODE>
 int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu1, const unsigned char *rowfree = nullptr,
-             const int *busy = nullptr, int nbusy = 0) {
+             const int *busy = nullptr, int nbusy = 0, bool exchange_f = false) {
     const G gg = g;
     if (!ctx().opt[3]) rowfree = nullptr;
+    if (exchange_f) WL_TRY((halo_begin<T>(g, const_cast<T *>(f), D, 1)));   // (in-stream when overlap is off)
     bool skip_free = false;   // the free rows were already done by the vector pass
     if constexpr (D == 3) {
         // two passes: (1) 16-B vector kernel streams u (+)= f on the body-free rows, (2) the scalar range kernel below
@@ -395,6 +415,7 @@ _Pragma("unroll")
                     uv.store(u + q);
                 }
             }, nullptr, nullptr);
+            WL_TRY(halo_end());
             if (rc > 0) return rc;
             if (rc == 0) skip_free = true;
             if (skip_free && busy) {   // compact list of busy interior rows (built by wl_flow_update): touch only those
@@ -408,6 +429,7 @@ _Pragma("unroll")
             }
         }
     }
+    WL_TRY(halo_end());
     return launch_range(WL_K_BDIM, r_inside(g), [=] __device__(int i, int j, int k) {
         const long I = gg.at(i, j, k);
         if (rowfree && rowfree[j + gg.n[1] * k]) {   // wave-uniform: a wavefront never spans two rows
