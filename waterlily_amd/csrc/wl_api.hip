@@ -326,13 +326,26 @@ template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, in
 }
 
 // project!  src/Flow.jl:137-145
-template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double dt_, double w, int *n_iter) {
+// exchange_u (z-slab runs, mom_step!): the 1-plane halo exchange of u that div needs (it reads u[I+dz]) is issued here on
+// the comm stream; x*=dt and div on all owned planes but the last run while it is in flight.
+template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double dt_, double w, int *n_iter, bool exchange_u = false) {
     const G g = mkG(&a->d.g);
     LevelT<T> p = lvl<T>(b, 0);
     const bool dbl = (w != 1.0);
     const double dts = dbl ? w * (double)(T)dt_ : (double)(T)dt_;
-    WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u)));
-    WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
+    const Range R = r_inside(g);
+    if (exchange_u && D == 3 && g.dist && overlap_on() && R.hi[2] - R.lo[2] + 1 >= 2) {
+        WL_TRY((halo_begin<T>(g, (T *)a->d.u, D, 1)));
+        WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
+        const int rc = op_div<T, D>(g, p.z, (const T *)a->d.u, R.lo[2], R.hi[2] - 1);
+        WL_TRY(halo_end());
+        if (rc) return rc;
+        WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u, R.hi[2], R.hi[2])));
+    } else {
+        if (exchange_u) WL_TRY((halo_exchange<T>(g, (T *)a->d.u, D, 1)));
+        WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u)));
+        WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
+    }
     WL_TRY((mg_solve<T, D>(b, 1e-4, 32, n_iter)));
     WL_TRY((op_correct<T, D>(g, (T *)a->d.u, p.L, p.x, p.rowc)));
     return op_scale_all<T, D>(g, p.x, dts, true, dbl);
@@ -354,15 +367,13 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true)));   // + exchange of f (overlapped)
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, u, u0, U, dt, a->sc.partials, a->sc.st)));
-    WL_TRY((halo_exchange<T>(g, u, D, 1)));
-    WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0])));
+    WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0], true)));   // + 1-plane exchange of u (overlapped with div)
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     // corrector (:164-167); the 2-plane exchange of u is issued inside op_conv_diff (overlapped with its inner planes)
     WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr, nullptr, true)));
     WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
-    WL_TRY((halo_exchange<T>(g, u, D, 1)));
-    WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1])));
+    WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     WL_TRY((halo_exchange<T>(g, u, D, 2)));
     // push!(a.dt, CFL(a)) (:168)

@@ -552,9 +552,11 @@ int op_scale_all(const G &g, T *a, double s, bool divide, bool dbl) {
 
 // @inside z[I] = div(I,u)  src/Flow.jl:11-17,139
 template <class T, int D>
-int op_div(const G &g, T *z, const T *u) {
+int op_div(const G &g, T *z, const T *u, int klo = 0, int khi = -1) {   // [klo,khi]: optional local plane sub-range
     const G gg = g;
-    return launch_range(WL_K_DIV, r_inside(g), [=] __device__(int i, int j, int k) {
+    Range R = r_inside(g);
+    if (khi >= klo) { R.lo[2] = klo > R.lo[2] ? klo : R.lo[2]; R.hi[2] = khi < R.hi[2] ? khi : R.hi[2]; }
+    return launch_range(WL_K_DIV, R, [=] __device__(int i, int j, int k) {
         const long I = gg.at(i, j, k);
         T s = 0;
 _Pragma("unroll")
