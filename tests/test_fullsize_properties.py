@@ -113,3 +113,28 @@ def test_hydrostatic_force_on_sphere(S):
     force = S.pressure_force_band(p, *S.band_to_device(p, idx, nds))
     vol = 4 / 3 * math.pi * R ** 3
     assert np.sum(np.abs(force / vol - np.array([0, 1, 0]))) < 2e-3
+
+
+def test_traffic_saving_switches_do_not_change_a_bit(S):
+    """The kernels that move fewer bytes than the dense algorithm -- row constants instead of L/iD in coefficient-
+    uniform rows (option 9), x += alpha*eps deferred to the direction kernel (8), z' = r*iD recomputed instead of
+    stored (13), body-free rows in BDIM! (3) -- evaluate the same expressions: three steps of the sphere case give
+    bit-identical u and p with all of them off."""
+    import bench
+    sims = []
+    for on in (1, 0):
+        for key in (3, 8, 9, 13):
+            S.set_option(key, on)
+        try:
+            sim = bench.sphere((N, N, N), T)
+            for _ in range(3):
+                S.sim_step(sim, remeasure=False)
+        finally:
+            for key in (3, 8, 9, 13):
+                S.set_option(key, 1)
+        sims.append(sim)
+    a, b = sims
+    nu, nr = S.uniform_rows(a.pois, 0)
+    assert nu > 0.8 * nr                      # most rows of the sphere case are coefficient-uniform
+    assert a.pois.n == b.pois.n and a.flow.dt == b.flow.dt
+    assert torch.equal(a.flow.u, b.flow.u) and torch.equal(a.flow.p, b.flow.p)
