@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="cells per side (BASELINE config: 512)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-size", type=int, default=192)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=30, help="timed steps of the CPU baseline (192^3: about 10 s on 16 cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layout", default="padded", choices=["padded", "dense"],
                     help="padded: rows 128-B aligned (default); dense: the reference's column-major layout (pitch N+2)")
