@@ -224,8 +224,10 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  * key 1: 1 = fused V-cycle smoothers (default), 0 = the reference's two-pass Jacobi!/increment!/prolongate!
  * key 2: 1 = LDS-tiled marching conv_diff kernel (default), 0 = generic gather kernel
  * key 3: 1 = BDIM! uses the body-free row flags (default), 0 = general path everywhere
- * key 5: 2 = 16-B vectorised streaming pcg kernels (default), 1 = additionally fuse direction into the next mult
- *        (set before wl_mg_create; measured: no gain at 512^3, slower at 256^3), 0 = scalar range kernels
+ * key 5: 2 = 16-B vectorised streaming pcg kernels (default), 1 = additionally evaluate the direction update (and the
+ *        deferred x update) inside the next mult kernel (set before wl_mg_create; bit-identical, measured SLOWER: the
+ *        fused kernel runs at the 7-point kernels' lower bandwidth, 1.12 ms vs 0.33 + 0.52 ms at 512^3), 0 = scalar
+ *        range kernels
  * key 6: 1 = multigrid levels <= 4096 cells run as one single-workgroup launch per V-cycle (default), 0 = per-op launches
  * key 7: 1 = BC! as one closed-form launch (default), 0 = the reference's sequence of plane loops
  * key 4: rows per workgroup of the vectorised 7-point kernel: 0 = 4 rows / 256 threads (default), 1 = 8 rows / 512

@@ -294,6 +294,26 @@ def test_uniform_rows_are_skipped_exactly(T):
 
 
 @pytest.mark.parametrize("T", TYPES)
+def test_pcg_fused_direction_variant(T):
+    """wl_set_option(5, 1) (set before the handle exists: it owns the ping-pong buffers): the direction update -- and
+    the deferred x update -- are evaluated inside the next mult kernel.  Same expressions => same bits as the default
+    three-kernel form, on a system with coefficient-uniform rows and on the :138 early exit."""
+    S.set_option(5, 1)
+    try:
+        _, ph1, x = _blob_system(T, O.MultiLevelPoisson, S.MultiLevelPoisson)
+        S.solver(ph1)
+    finally:
+        S.set_option(5, 2)
+    po, ph2, _ = _blob_system(T, O.MultiLevelPoisson, S.MultiLevelPoisson)
+    S.solver(ph2)
+    O.solver(po)
+    assert ph1.n == ph2.n == po.n
+    assert np.array_equal(S.to_host(ph1.x), S.to_host(ph2.x))
+    assert np.array_equal(S.to_host(lev_h(ph1).r), S.to_host(lev_h(ph2).r))
+    same(ph1.x, po.x, exact=False, tol=10 * rtol(T))
+
+
+@pytest.mark.parametrize("T", TYPES)
 def test_single_level_poisson_solver(T):
     po, ph = make_pois((18, 18), T, O.Poisson, S.Poisson)
     O.solver(po)

@@ -18,6 +18,9 @@ T = np.float64 if "--f64" in sys.argv else np.float32
 size, key = int(argv[0]), int(argv[1])
 vals = [int(v) for v in argv[2:]]
 L = _lib.lib()
+for kv in os.environ.get("WL_PRESET", "").split(","):   # options that must be set BEFORE the handles are created, "5=1,..."
+    if "=" in kv:
+        _lib.check(L.wl_set_option(int(kv.split("=")[0]), int(kv.split("=")[1])))
 sim = bench.sphere((size,) * 3, T)
 names = {L.wl_kernel_name(k).decode(): k for k in range(24)}
 for _ in range(int(os.environ.get("WL_PRESTEPS", "30"))):
@@ -37,4 +40,10 @@ for rep in range(2):
             _lib.check(L.wl_prof_timed(C.byref(nl), C.byref(nc), C.byref(ms)))
             row.append(ms.value / max(1, nl.value))
         _lib.check(L.wl_prof_select(-1, 0))
-        print(f"{v:5d}  " + "  ".join(f"{t:13.3f}" for t in row))
+        import time as _t
+        import torch as _torch
+        _torch.cuda.synchronize(); t0 = _t.perf_counter()
+        for _ in range(3):
+            S.sim_step(sim, remeasure=False)
+        _torch.cuda.synchronize()
+        print(f"{v:5d}  " + "  ".join(f"{t:13.3f}" for t in row) + f"   step {(_t.perf_counter() - t0) / 3 * 1e3:7.2f} ms")

@@ -909,10 +909,10 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     const bool fusedir = vec && scratch && permask == 0 && !p.g.dist && ctx().opt[5] == 1 && ctx().opt[0] && stencil7_ok<T>(p.g, scratch, p.L) &&
                          (long)((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 7) / 4) + 8 <= WL_MAXB;
     T *ecur = p.eps, *eoth = scratch;   // (fusedir) buffer holding the current / next search direction
-    const bool xdef = ctx().opt[8] != 0 && !fusedir;
+    const bool xdef = ctx().opt[8] != 0;
     // z' = r*iD (:136) is not stored (wl_set_option(13), default on): the direction kernel recomputes it from r and iD
     // (iD is a row constant away from the body), one array write + one read less per iteration; z keeps A*eps.
-    const bool zrec = ctx().opt[13] != 0 && !fusedir;
+    const bool zrec = ctx().opt[13] != 0 || fusedir;
     // :125-127
     int rv0 = -1;
     if (vec) {
@@ -952,15 +952,27 @@ _Pragma("unroll")
             if (stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.z, p.L)) {
                 using VA = VecA<T>;
                 if (fusedir && n > 1) {   // (never on a decomposed level: no exchange needed)
-                    // :140 of the previous iteration + :130-131: eps_new = beta*eps + r*iD (out of place), z = A eps_new
+                    // [:133 x += alpha*eps of the previous iteration (deferred)] + :140 of the previous iteration +
+                    // :130-131: eps_new = beta*eps + r*iD (out of place: neighbours still read the old eps), z = A eps_new
                     T *eo = eoth;
-                    rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g, SrcDirection<T>{ecur, p.r, p.iD, &st->beta}, p.L, p.rowc,
-                        [=] __device__(long o, const VA &ae, const VA &ec, double *acc, const Pre &) {
+                    const T *eold = ecur;
+                    rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g,
+                        SrcDirection<T>{ecur, p.r, p.iD, p.rowc, p.g.n[0], p.g.n[1], (T)0}, p.L, p.rowc,
+                        [=] __device__(long o, const VA &ae, const VA &ec, double *acc, const Pre &pre) {
+                            if (xdef) {
+                                const T alpha = (T)pre.s0;
+                                const VA ev = VA::load(eold + o);
+                                VA xv = VA::load(q.x + o);
+_Pragma("unroll")
+                                for (int v = 0; v < VA::V; ++v) xv.v[v] += alpha * ev.v[v];
+                                xv.store(q.x + o);
+                                if (!pre.act) return;   // only the x update of the :138 exit was owed
+                            }
                             ec.store(eo + o);
                             ae.store(q.z + o);
 _Pragma("unroll")
                             for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];
-                        }, partials, &np, Gate{&st->active});
+                        }, partials, &np, Gate{&st->active, xdef ? &st->xpend : nullptr, &st->alpha, &st->beta});
                     if (rcv == 0) { T *tmp = ecur; ecur = eoth; eoth = tmp; }
                 } else {
                 const T *esrc = ecur;
@@ -1017,7 +1029,7 @@ _Pragma("unroll")
                     VA zn;
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) { zn.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zn.v[v]; }
-                    if (!fusedir && !zrec) zn.store(q.z + o);   // (else) the direction kernel recomputes r*iD: z' is never stored
+                    if (!zrec) zn.store(q.z + o);   // (else) the direction kernel recomputes r*iD: z' is never stored
                 } else if (want_r2) {
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) acc[0] += (double)rr.v[v] * (double)rr.v[v];

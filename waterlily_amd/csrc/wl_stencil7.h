@@ -49,9 +49,29 @@ template <class T> struct VecA {   // array view of a 16-B vector
 
 constexpr int S7_BY = 4;   // rows (= wavefronts) per workgroup of the helper kernels (k_correct3)
 
+// Device-side gate and scalars of a solver kernel, read ONCE per thread before its z loop (uniform addresses): inside
+// the loop they would be re-loaded every plane (the stores in between may alias them as far as the compiler knows),
+// each time draining the loads in flight.  The body runs when no gate is given, when *active != 0, or when `also` is
+// given and *also != 0.  s0/s1: optional device scalars (alpha, beta) handed to the functor.
+struct Gate {
+    const int *active = nullptr, *also = nullptr;
+    const double *s0 = nullptr, *s1 = nullptr;
+};
+struct Pre { int act; double s0, s1; };
+__device__ __forceinline__ bool gate_open(const Gate &gt, Pre &pre) {
+    pre.act = 1; pre.s0 = 0.0; pre.s1 = 0.0;
+    bool run = true;
+    if (gt.active) { pre.act = *gt.active; run = pre.act || (gt.also && *gt.also); }
+    if (gt.s0) pre.s0 = *gt.s0;
+    if (gt.s1) pre.s1 = *gt.s1;
+    return run;
+}
+
 // ---- stencil operand sources: vec(o,i,j,k) = the V cells starting at (i,j,k) [offset o], scal = one cell
+// init(pre): called once per thread before the z loop with the gate's scalars (only SrcDirection uses them)
 template <class T> struct SrcArray {          // e is an array (pcg!: eps, residual!: x, increment!: eps)
     const T *e;
+    __device__ __forceinline__ void init(const Pre &) {}
     __device__ __forceinline__ VecA<T> vec(long o, int, int, int) const { return VecA<T>::load(e + o); }
     __device__ __forceinline__ T scal(long o, int, int, int) const { return e[o]; }
 };
@@ -97,6 +117,7 @@ template <class T> struct SrcJacobi {         // e = r*iD evaluated on the fly (
     const T *r, *iD;
     const T *rowc;                             // row constants (nullptr: none)
     int n0, n1;
+    __device__ __forceinline__ void init(const Pre &) {}
     __device__ __forceinline__ VecA<T> vec(long o, int i, int j, int k) const {
         const VecA<T> a = VecA<T>::load(r + o), b = load_iD<T>(iD, rowc, n0, n1, o, i, j, k);
         VecA<T> c;
@@ -108,21 +129,24 @@ template <class T> struct SrcJacobi {         // e = r*iD evaluated on the fly (
 };
 template <class T> struct SrcDirection {      // e = beta*eps + r*iD : pcg!'s new search direction on the fly (Poisson.jl:136,140)
     const T *e, *r, *iD;
-    const double *beta;                        // device scalar, already rounded to T
-    __device__ __forceinline__ VecA<T> vec(long o, int, int, int) const {
-        const T b = (T)*beta;
-        const VecA<T> ev = VecA<T>::load(e + o), rv = VecA<T>::load(r + o), dv = VecA<T>::load(iD + o);
+    const T *rowc;                             // row constants (nullptr: none)
+    int n0, n1;
+    T b;                                       // beta: taken from the gate's second scalar by init()
+    __device__ __forceinline__ void init(const Pre &pre) { b = (T)pre.s1; }
+    __device__ __forceinline__ VecA<T> vec(long o, int i, int j, int k) const {
+        const VecA<T> ev = VecA<T>::load(e + o), rv = VecA<T>::load(r + o), dv = load_iD<T>(iD, rowc, n0, n1, o, i, j, k);
         VecA<T> c;
 #pragma unroll
         for (int v = 0; v < VecA<T>::V; ++v) c.v[v] = b * ev.v[v] + rv.v[v] * dv.v[v];
         return c;
     }
-    __device__ __forceinline__ T scal(long o, int, int, int) const { return (T)*beta * e[o] + r[o] * iD[o]; }
+    __device__ __forceinline__ T scal(long o, int, int, int) const { return b * e[o] + r[o] * iD[o]; }
 };
 template <class T> struct SrcProlong {        // e[I] = coarse x[down(I)] inside, 0 on ghosts (MultiLevelPoisson.jl:2,34)
     const T *cx;
     G C;            // coarse grid
     int n0, n1, nzg, kz0;   // fine extents (global along z) and the fine grid's kz0
+    __device__ __forceinline__ void init(const Pre &) {}
     __device__ __forceinline__ T scal(long, int i, int j, int k) const {
         const int kg = k + kz0;
         if (i < 1 || i > n0 - 2 || j < 1 || j > n1 - 2 || kg < 1 || kg > nzg - 2) return (T)0;
@@ -143,24 +167,6 @@ template <class T> struct SrcProlong {        // e[I] = coarse x[down(I)] inside
     }
 };
 
-// Device-side gate and scalars of a solver kernel, read ONCE per thread before its z loop (uniform addresses): inside
-// the loop they would be re-loaded every plane (the stores in between may alias them as far as the compiler knows),
-// each time draining the loads in flight.  The body runs when no gate is given, when *active != 0, or when `also` is
-// given and *also != 0.  s0/s1: optional device scalars (alpha, beta) handed to the functor.
-struct Gate {
-    const int *active = nullptr, *also = nullptr;
-    const double *s0 = nullptr, *s1 = nullptr;
-};
-struct Pre { int act; double s0, s1; };
-__device__ __forceinline__ bool gate_open(const Gate &gt, Pre &pre) {
-    pre.act = 1; pre.s0 = 0.0; pre.s1 = 0.0;
-    bool run = true;
-    if (gt.active) { pre.act = *gt.active; run = pre.act || (gt.also && *gt.also); }
-    if (gt.s0) pre.s0 = *gt.s0;
-    if (gt.s1) pre.s1 = *gt.s1;
-    return run;
-}
-
 template <class T, int NRED, int BY, class SRC, class EPI>
 __global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__restrict__ L, const T *__restrict__ rowc, EPI epi,
                                                   double *partials, int ntx, int tpp, int nblk, int clen, int klo,
@@ -180,6 +186,7 @@ __global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__r
     for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) acc[q] = 0.0;
     Pre pre;
     const bool run = gate_open(gate, pre);
+    src.init(pre);
     const bool active = run && (i <= nxi) && (j <= nyi) && (k0 < k1);
     if (active) {   // (no barriers below: inactive lanes may simply skip; shuffles only pair active lanes)
         const bool first = (lane == 0), last = (lane == 63) || (i + V > nxi);
