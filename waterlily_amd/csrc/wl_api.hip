@@ -13,8 +13,13 @@ namespace wl {
 // RCCL over xGMI: neighbour send/recv pairs and world collectives, enqueued on the compute stream (so they are
 // ordered with the kernels that produce/consume the planes without host synchronisation).
 struct RcclComm : Comm {
-    ncclComm_t nc = nullptr;
-    ~RcclComm() override { if (nc) ncclCommDestroy(nc); }
+    ncclComm_t nc = nullptr;    // world collectives (all-reduce, all-gather), always on the compute stream
+    ncclComm_t nch = nullptr;   // halo send/recv: a split of `nc`, so that exchanges running on the comm stream (halo_begin)
+                                // never share a communicator with a collective on the compute stream; == nullptr: use nc
+    ~RcclComm() override {
+        if (nch) ncclCommDestroy(nch);
+        if (nc) ncclCommDestroy(nc);
+    }
     int chk(ncclResult_t r, const char *what) {
         if (r == ncclSuccess) return 0;
         ctx().err = std::string("rccl: ") + what + ": " + ncclGetErrorString(r);
@@ -28,10 +33,11 @@ struct RcclComm : Comm {
         if (rc) return rc;
         // order: my upper planes go up and fill the lower halo of peer_hi, whose first receive from me is its recv_lo, ...
         // (with a 2-rank ring both peers are the same rank: k-th send must meet the k-th receive of that peer)
-        if (shi) ncclSend(shi, bytes, ncclChar, phi, nc, ctx().stream);
-        if (rlo) ncclRecv(rlo, bytes, ncclChar, plo, nc, ctx().stream);
-        if (slo) ncclSend(slo, bytes, ncclChar, plo, nc, ctx().stream);
-        if (rhi) ncclRecv(rhi, bytes, ncclChar, phi, nc, ctx().stream);
+        ncclComm_t h = nch ? nch : nc;
+        if (shi) ncclSend(shi, bytes, ncclChar, phi, h, ctx().stream);
+        if (rlo) ncclRecv(rlo, bytes, ncclChar, plo, h, ctx().stream);
+        if (slo) ncclSend(slo, bytes, ncclChar, plo, h, ctx().stream);
+        if (rhi) ncclRecv(rhi, bytes, ncclChar, phi, h, ctx().stream);
         return chk(ncclGroupEnd(), "groupEnd(sendrecv)");
     }
     int allgather(void *buf, size_t bytes) override {
@@ -611,6 +617,11 @@ int wl_comm_init_rccl(const void *id128, int rank, int nranks) {
     c->rank = rank; c->size = nranks;
     ncclResult_t r = ncclCommInitRank(&c->nc, nranks, id, rank);
     if (r != ncclSuccess) { delete c; return fail(WL_E_STATE, ncclGetErrorString(r), __FILE__, __LINE__); }
+    const char *ov = getenv("WL_OVERLAP");
+    if (!(ov && ov[0] == '0')) {   // overlapped exchanges get their own communicator (same ranks); on failure they share `nc`
+        ncclComm_t h = nullptr;
+        if (ncclCommSplit(c->nc, 0, rank, &h, nullptr) == ncclSuccess && h) c->nch = h;
+    }
     ctx().comm = c;
     return 0;
 }
@@ -624,7 +635,12 @@ int wl_comm_init_host(int rank, int nranks, wl_host_sendrecv_fn sr, wl_host_allr
     return 0;
 }
 int wl_comm_finalize(void) {
-    if (ctx().comm) { (void)hipStreamSynchronize(ctx().stream); delete ctx().comm; ctx().comm = nullptr; }
+    if (ctx().comm) {
+        (void)hipStreamSynchronize(ctx().stream);
+        if (ctx().cstream) (void)hipStreamSynchronize(ctx().cstream);
+        delete ctx().comm;
+        ctx().comm = nullptr;
+    }
     return 0;
 }
 int wl_comm_rank(int *rank, int *nranks) {
