@@ -179,6 +179,17 @@ def _chunk_points(Ng, lo, hi, device):
     return torch.stack([q.reshape(-1) for q in g]), shp
 
 
+def _fill_whole(a: "torch.Tensor", value) -> None:
+    """a.fill_(value).  A padded field (sim.Layout.alloc) is a strided view of ONE flat buffer of its own; filling the
+    view runs torch's generic strided kernel (0.9 ms per 512^3 component), filling the flat buffer -- row padding
+    included, nothing reads it -- is a plain memset-speed stream (15 components: 14 ms -> 2 ms per measure!)."""
+    base = a._base
+    if base is not None and base.dim() == 1 and base.is_contiguous() and a.numel() <= base.numel() <= 2 * a.numel():
+        base.fill_(value)
+    else:
+        a.fill_(value)
+
+
 def measure_fields_into(body, dims: Sequence[int], mu0, mu1, V, dsdf, t: float = 0.0, eps: float = 1.0,
                         chunk_cells: Optional[int] = None, slab=None):
     """Body.jl:31-50 before the two BC! calls, written INTO the given torch tensors (any device, any strides):
@@ -197,9 +208,9 @@ def measure_fields_into(body, dims: Sequence[int], mu0, mu1, V, dsdf, t: float =
     cand = []
     kz0 = slab.kz0 if slab is not None else 0
     nl = mu0.shape[D - 1]
-    mu0.fill_(1)
-    mu1.zero_()
-    V.zero_()
+    _fill_whole(mu0, 1)
+    _fill_whole(mu1, 0)
+    _fill_whole(V, 0)
     if body is None or isinstance(body, NoBody):
         return torch.zeros(0, dtype=torch.int64, device=dev)
     d2 = float((2 + eps) ** 2)
