@@ -381,9 +381,8 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
-    WL_TRY((halo_exchange<T>(g, u, D, 2)));
-    // push!(a.dt, CFL(a)) (:168)
-    WL_TRY((op_cfl<T, D>(g, (T *)d.sigma, u, d.nu, a->sc.partials, a->sc.st)));
+    // push!(a.dt, CFL(a)) (:168); the end-of-step 2-plane exchange of u is issued inside (overlapped with the kernel)
+    WL_TRY((op_cfl<T, D>(g, (T *)d.sigma, u, d.nu, a->sc.partials, a->sc.st, true)));
     WL_TRY(a->sc.fetch());
     *dt_next = a->sc.hst->out[0];
     return 0;

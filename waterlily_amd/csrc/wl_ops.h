@@ -649,11 +649,14 @@ _Pragma("unroll")
 // CFL  src/Flow.jl:172-182: sigma = flux_out (Float64 via max(0.,.)), dt = min(10, inv(max(sigma)+5nu)).
 // The max runs over inside(sigma): the reference's maximum(a.sigma) also sees ghost cells, which only hold
 // stale flux scratch of conv_diff! (sigma doubles as Phi) -- see DESIGN.md "Deliberate deviations".
+// exchange_u (z-slab runs, mom_step!): the end-of-step 2-plane halo exchange of u (it feeds this kernel's u[I+dz] on the last
+// owned plane and the next step's conv_diff!) is issued here on the comm stream; all owned planes but the last are
+// processed while it is in flight.
 template <class T, int D>
-int op_cfl(const G &g, T *sigma, const T *u, double nu_, double *partials, State *st) {
+int op_cfl(const G &g, T *sigma, const T *u, double nu_, double *partials, State *st, bool exchange_u = false) {
     const G gg = g;
     int np = 0;
-    WL_TRY((launch_range_red<1>(WL_K_CFL, r_inside(g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
+    auto body = [=] __device__(int i, int j, int k, double(&acc)[1]) {
         const long I = gg.at(i, j, k);
         double s = 0;
 _Pragma("unroll")
@@ -664,7 +667,23 @@ _Pragma("unroll")
         const T sg = (T)s;
         sigma[I] = sg;
         acc[0] = (double)sg > acc[0] ? (double)sg : acc[0];
-    }, partials, RED_MAX, -1e300, &np)));
+    };
+    const Range R = r_inside(g);
+    if (exchange_u && D == 3 && g.dist && overlap_on() && R.hi[2] - R.lo[2] + 1 >= 2) {
+        WL_TRY((halo_begin<T>(g, const_cast<T *>(u), D, 2)));
+        Range Ra = R, Rb = R;
+        Ra.hi[2] = R.hi[2] - 1;
+        Rb.lo[2] = R.hi[2];
+        int n1 = 0, n2 = 0;
+        const int rc = launch_range_red<1>(WL_K_CFL, Ra, body, partials, RED_MAX, -1e300, &n1);
+        WL_TRY(halo_end());
+        if (rc) return rc;
+        WL_TRY((launch_range_red<1>(WL_K_CFL, Rb, body, partials + n1, RED_MAX, -1e300, &n2)));
+        np = n1 + n2;
+    } else {
+        if (exchange_u) WL_TRY((halo_exchange<T>(g, const_cast<T *>(u), D, 2)));
+        WL_TRY((launch_range_red<1>(WL_K_CFL, R, body, partials, RED_MAX, -1e300, &np)));
+    }
     const T nu5 = (T)5 * (T)nu_;
     return launch_finalize<1>(g.dist, partials, np, RED_MAX, -1e300, st->red, [=] __device__(const double *v) {
         const T d = (T)1 / ((T)v[0] + nu5);
