@@ -218,6 +218,19 @@ def main():
             traffic = json.load(open(tfile)).get(f"{dominant}@{m}^3/{args.dtype}") if not args.grid else None
         except Exception:
             traffic = None
+    # the north-star's named kernel: the V-cycle smoother (fused Jacobi!+increment! and prolongate!+increment!), from
+    # the per-class hipEvent pass above (finest-level launches only)
+    smoother = None
+    if per_class.get("smooth", {}).get("launches"):
+        sm = per_class["smooth"]
+        sm_ms = sm["ms"] / sm["launches"]
+        d_, n_, k_ = ALG_T["smooth"]
+        sm_alg = d_ * tsz * ncell
+        sm_mov = (d_ - n_ - phi * k_) * tsz * ncell
+        smoother = {"kernel": "smooth", "avg_launch_ms": sm_ms, "launches": sm["launches"],
+                    "achieved": sm_alg / (sm_ms * 1e-3) / 1e9, "frac": sm_alg / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "moved_GB/s": sm_mov / (sm_ms * 1e-3) / 1e9, "moved_frac": sm_mov / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "unit": "GB/s", "algorithmic_bytes_per_launch": sm_alg}
     out = {
         "metric": "MLUPS (cell-updates/s) per sim_step!, 3D sphere", "value": mlups, "unit": "MLUPS",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -235,7 +248,7 @@ def main():
                                "note": "achieved/frac use the dense algorithmic bytes of SURVEY 8(d); the kernel skips the "
                                        "loads of L/iD in coefficient-uniform rows and recomputes D, so it moves only "
                                        "`moved.bytes_per_launch` (compare `traffic`, the PMC-measured bytes)"},
-                     "per_class_ms_one_step": per_class},
+                     "smoother": smoother, "per_class_ms_one_step": per_class},
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps)
