@@ -70,6 +70,21 @@ def sphere(dims, T, Re=3700.0, device="cuda:0", padded=True):
                         padded=padded)
 
 
+def donut(dims, T, Re=1000.0, device="cuda:0", padded=True):
+    """BASELINE configs[4]: torus sdf(x) = |(x1-c, |(x2-c, x3-c)| - R)| - r, c = m/2, R = m/4, r = m/16,
+    L = R, Re = 1000 (the reference only links its donut example, README.md:53)."""
+    import torch
+    from waterlily_amd import sim as S
+    from waterlily_amd.body import AutoBody
+    m = min(dims)
+    c, R, r = m / 2, m / 4, m / 16
+
+    def sdf(x, t):
+        ring = torch.sqrt((x[1] - c) ** 2 + (x[2] - dims[2] / 2) ** 2) - R
+        return torch.sqrt((x[0] - c) ** 2 + ring ** 2) - r
+    return S.Simulation(tuple(dims), (1.0, 0.0, 0.0), R, nu=R / Re, body=AutoBody(sdf), T=T, device=device, padded=padded)
+
+
 def cpu_baseline(size: int, steps: int):
     """The CPU restatement of the reference (oracle/, OpenMP) timed on the host cores on a bounded sample."""
     from oracle import wl_oracle as O
@@ -113,6 +128,7 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=192)
     ap.add_argument("--cpu-steps", type=int, default=30, help="timed steps of the CPU baseline (192^3: about 10 s on 16 cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--body", default="sphere", choices=["sphere", "donut"], help="donut: BASELINE configs[4] (use with --dtype f64)")
     ap.add_argument("--layout", default="padded", choices=["padded", "dense"],
                     help="padded: rows 128-B aligned (default); dense: the reference's column-major layout (pitch N+2)")
     ap.add_argument("--kernel", default=None, help="force the kernel class reported in `roofline`")
@@ -153,7 +169,7 @@ def main():
     # global grid is 512 x 512 x 512N; --grid gives an explicit global grid instead (strong scaling).
     dims = tuple(args.grid) if args.grid else (m, m, m * world)
     scaling = "strong" if args.grid else "weak"
-    sim = sphere(dims, T, device=dev, padded=(args.layout == "padded"))
+    sim = (sphere if args.body == "sphere" else donut)(dims, T, device=dev, padded=(args.layout == "padded"))
     ncell_global = int(np.prod(dims))
     ncell = ncell_global // world            # cells per rank: threshold for "finest level" launches
     names = class_table(L)
@@ -235,9 +251,9 @@ def main():
         "metric": "MLUPS (cell-updates/s) per sim_step!, 3D sphere", "value": mlups, "unit": "MLUPS",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"3D sphere {dims[0]}x{dims[1]}x{dims[2]}, Re=3700, {args.dtype}, uniform inflow, "
+        "config": {"workload": f"3D {args.body} {dims[0]}x{dims[1]}x{dims[2]}, Re={3700 if args.body == 'sphere' else 1000}, {args.dtype}, uniform inflow, "
                                f"remeasure=false" + (", dense layout" if args.layout == "dense" else "") + (" (BASELINE configs[2])" if world == 1 and not args.grid and m == 512
-                                                     and args.dtype == "f32" else "" if world == 1 else
+                                                     and args.dtype == "f32" and args.body == "sphere" else "" if world == 1 else
                                                      f", z-slabs over {world} GPUs (RCCL halo exchange)"),
                    "vcycles_per_solve": vcycles[:6], "mean_vcycles_per_step": float(np.sum(vcycles)) / args.steps},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
