@@ -24,6 +24,7 @@ struct State {
     int nupd;                 // number of (x,r) updates pcg performed
     int r2_valid;             // the last pcg! update already produced r.r (solver! can skip the separate L2 pass)
     int xpend;                // pcg stopped at :138 with x += alpha*eps still owed (deferred-x form, see op_pcg)
+    PcgS slots[2];            // pcg!'s scalars while its kernels evaluate them themselves (Gate kind 1..4, wl_stencil7.h)
 };
 
 template <class T> struct LevelT {
@@ -932,6 +933,24 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     // z' = r*iD (:136) is not stored (wl_set_option(13), default on): the direction kernel recomputes it from r and iD
     // (iD is a row constant away from the body), one array write + one read less per iteration; z keeps A*eps.
     const bool zrec = ctx().opt[13] != 0 || fusedir;
+    // No finalize launches (wl_set_option(15), default on; single rank, default kernel forms): the dot products z.eps and
+    // r.z' are finished by the NEXT kernel (every workgroup sums the <= 1024 partials and applies the scalar logic, Gate
+    // kind 1..3), the state travels through st->slots; only the last update keeps its finalize (it publishes the state).
+    // Levels above 2^25 cells keep the finalize launches (option 15 = 1; 2 = always): there the cap on the number of
+    // workgroups that keeps the in-kernel sums cheap costs the streaming kernels more than the launches it saves
+    // (512^3: +0.8 %; 256^3 and every coarser level: -2.8 %).
+    const int tpp_v = D == 3 ? (((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 3) / 4) + 7) / 8 * 8 : 0;
+    const bool infin = vec && xdef && zrec && !fusedir && !ctx().opt[4] && R.count() > 0 && tpp_v > 0 &&
+                       (ctx().opt[15] == 2 || (ctx().opt[15] == 1 && R.count() <= (1L << 25))) &&
+                       tpp_v <= 1024 && !(p.g.dist && ctx().comm && ctx().comm->size > 1);
+    struct CapGuard {   // the in-kernel sums want few partials: cap the number of z-chunks for the kernels of this call
+        int o11, o12; bool on;
+        CapGuard(bool on_, int cap) : o11(ctx().opt[11]), o12(ctx().opt[12]), on(on_) { if (on) { ctx().opt[11] = cap; ctx().opt[12] = cap; } }
+        ~CapGuard() { if (on) { ctx().opt[11] = o11; ctx().opt[12] = o12; } }
+    } capguard(infin, infin ? (1024 / tpp_v > 0 ? 1024 / tpp_v : 1) : 0);
+    double *P0 = partials, *PA = infin ? partials + WL_MAXB : partials, *PB = infin ? partials + 2 * WL_MAXB : partials;
+    const int f32 = sizeof(T) == 4;
+    int np0 = 0, npA = 0, cur = 0;   // cur: the slot holding the current state
     // :125-127
     int rv0 = -1;
     if (vec) {
@@ -943,9 +962,11 @@ _Pragma("unroll")
             for (int v = 0; v < VA::V; ++v) { zv.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zv.v[v]; }
             if (!zrec) zv.store(q.z + o);
             zv.store(q.eps + o);
-        }, partials, &np);
+        }, P0, &np);
         if (rv0 > 0) return rv0;
+        np0 = np;
     }
+    if (infin && rv0 != 0) return fail(WL_E_STATE, "pcg: vector init kernel rejected", __FILE__, __LINE__);
     if (rv0 != 0)
     WL_TRY((launch_range_red<1>(WL_K_PCG_INIT, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
         const long I = q.g.at(i, j, k);
@@ -954,6 +975,7 @@ _Pragma("unroll")
         q.eps[I] = v;
         acc[0] += (double)q.r[I] * (double)v;
     }, partials, RED_SUM, 0.0, &np)));
+    if (!infin)
     WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
         const T rho = (T)v[0];
         st->rho = (double)rho;
@@ -996,14 +1018,21 @@ _Pragma("unroll")
                 } else {
                 const T *esrc = ecur;
                 exchanged = true;
+                Gate gate_mult;
+                if (!infin) gate_mult.active = &st->active;
+                else if (n == 1) { gate_mult.kind = 1; gate_mult.part = P0; gate_mult.np = np0; gate_mult.out = &st->slots[0]; cur = 0; }
+                else { gate_mult.kind = 4; gate_mult.in = &st->slots[cur]; }
+                gate_mult.eps10 = (double)eps10; gate_mult.f32 = f32;
                 rcv = launch_stencil7_halo<T, 1>(WL_K_PCG_MULT, p.g, ecur, SrcArray<T>{esrc}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
                     [=] __device__(long o, const VA &ae, const VA &ec, const VA &, const VA &, double *acc, const Pre &) {
                     ae.store(q.z + o);
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];
-                }, partials, &np, Gate{&st->active});
+                }, PA, &np, gate_mult);
                 }
                 if (rcv > 0) return rcv;
+                if (infin && rcv != 0) return fail(WL_E_STATE, "pcg: vector mult kernel rejected", __FILE__, __LINE__);
+                npA = np;
             }
         }
         if (!exchanged) WL_TRY((halo_exchange<T>(p.g, p.eps, 1, 1)));
@@ -1015,6 +1044,7 @@ _Pragma("unroll")
             q.z[I] = v;
             acc[0] += (double)v * (double)q.eps[I];
         }, partials, RED_SUM, 0.0, &np)));
+        if (!infin)
         WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
             st->xpend = 0;   // any owed x update was applied by the direction kernel before this mult
             if (!st->active) return;
@@ -1027,6 +1057,10 @@ _Pragma("unroll")
         const bool xnow = last || !xdef;   // x += alpha*eps in the update kernel (else in the direction kernel)
         // :133-137
         int rvu = -1;
+        Gate gate_upd;
+        if (!infin) { gate_upd.active = &st->active; gate_upd.s0 = &st->alpha; }
+        else { gate_upd.kind = 2; gate_upd.part = PA; gate_upd.np = npA; gate_upd.in = &st->slots[cur]; gate_upd.out = &st->slots[cur ^ 1]; }
+        gate_upd.eps10 = (double)eps10; gate_upd.f32 = f32;
         if (vec) {
             rvu = launch_rowvec<T, 1>(WL_K_PCG_UPDATE, p.g, [=] __device__(long o, int j, int k, double *acc, const Pre &pre) {
                 const T alpha = (T)pre.s0;
@@ -1053,8 +1087,10 @@ _Pragma("unroll")
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) acc[0] += (double)rr.v[v] * (double)rr.v[v];
                 }
-            }, partials, &np, Gate{&st->active, nullptr, &st->alpha});
+            }, PB, &np, gate_upd);
             if (rvu > 0) return rvu;
+            if (infin && rvu != 0) return fail(WL_E_STATE, "pcg: vector update kernel rejected", __FILE__, __LINE__);
+            if (infin) cur ^= 1;
         }
         if (rvu != 0)
         WL_TRY((launch_range_red<1>(WL_K_PCG_UPDATE, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
@@ -1072,6 +1108,23 @@ _Pragma("unroll")
                 acc[0] += (double)rn * (double)rn;
             }
         }, partials, RED_SUM, 0.0, &np)));
+        if (infin) {
+            if (last) {   // the one finalize of the call: finishes r.r (:135) and publishes the state for the host / L2
+                const int cs = cur;
+                WL_TRY((launch_finalize<1>(false, PB, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
+                    PcgS sl = st->slots[cs];
+                    if (sl.active) {
+                        sl.nupd += 1;
+                        if (want_r2) { sl.r2 = (double)(T)v[0]; sl.r2_valid = 1; }
+                        sl.active = 0;
+                    }
+                    st->rho = sl.rho; st->alpha = sl.alpha; st->beta = sl.beta;
+                    st->active = sl.active; st->xpend = sl.xpend; st->nupd = sl.nupd;
+                    st->r2_valid = sl.r2_valid;
+                    if (sl.r2_valid) st->r2 = sl.r2;
+                })));
+            }
+        } else
         WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
             if (!st->active) return;
             st->nupd += 1;
@@ -1089,6 +1142,10 @@ _Pragma("unroll")
         // :140
         if (fusedir) continue;   // folded into the next iteration's mult kernel
         int rvd = -1;
+        Gate gate_dir;
+        if (!infin) { gate_dir.active = &st->active; gate_dir.also = xdef ? &st->xpend : nullptr; gate_dir.s0 = &st->alpha; gate_dir.s1 = &st->beta; }
+        else { gate_dir.kind = 3; gate_dir.part = PB; gate_dir.np = np; gate_dir.in = &st->slots[cur]; gate_dir.out = &st->slots[cur ^ 1]; gate_dir.also_x = 1; }
+        gate_dir.eps10 = (double)eps10; gate_dir.f32 = f32;
         if (vec) {
             rvd = launch_rowvec<T, 0>(WL_K_PCG_DIR, p.g, [=] __device__(long o, int j, int k, double *, const Pre &pre) {
                 // gate: runs when pcg is active, or (deferred x) when only the x update of the :138 exit is owed
@@ -1114,8 +1171,10 @@ _Pragma("unroll")
 _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) ev.v[v] = beta * ev.v[v] + zv.v[v];
                 ev.store(q.eps + o);
-            }, nullptr, nullptr, Gate{&st->active, xdef ? &st->xpend : nullptr, &st->alpha, &st->beta});
+            }, nullptr, nullptr, gate_dir);
             if (rvd > 0) return rvd;
+            if (infin && rvd != 0) return fail(WL_E_STATE, "pcg: vector direction kernel rejected", __FILE__, __LINE__);
+            if (infin) cur ^= 1;
         }
         if (rvd != 0)
         WL_TRY(launch_range(WL_K_PCG_DIR, R, [=] __device__(int i, int j, int k) {

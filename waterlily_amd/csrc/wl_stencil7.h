@@ -51,20 +51,85 @@ constexpr int S7_BY = 4;   // rows (= wavefronts) per workgroup of the helper ke
 
 // Device-side gate and scalars of a solver kernel, read ONCE per thread before its z loop (uniform addresses): inside
 // the loop they would be re-loaded every plane (the stores in between may alias them as far as the compiler knows),
-// each time draining the loads in flight.  The body runs when no gate is given, when *active != 0, or when `also` is
-// given and *also != 0.  s0/s1: optional device scalars (alpha, beta) handed to the functor.
+// each time draining the loads in flight.
+//   kind 0: the body runs when no gate is given, when *active != 0, or when `also` is given and *also != 0; s0/s1 are
+//           optional device scalars (alpha, beta) handed to the functor.
+//   kind 1..4 (pcg! without the one-workgroup finalize launches): the kernel ITSELF finishes the dot product of the
+//           kernel before it -- every workgroup sums that kernel's per-workgroup partials in the fixed order of k_finalize
+//           (<= 1024 doubles, L2-resident) and applies pcg!'s scalar logic (src/Poisson.jl:127,131-132,137-139) to the
+//           state it reads from slot `in`; the first thread of the grid stores the new state to the OTHER slot `out`
+//           (nobody reads that one during this kernel), from where the next kernel picks it up.
+//           1: after the init kernel (rho, :126-127)   2: after mult (alpha, :131-132)
+//           3: after a non-final update (rho2, beta, :137-139)   4: read the state only
+struct PcgS { double rho, alpha, beta, r2; int active, xpend, nupd, r2_valid; };
 struct Gate {
     const int *active = nullptr, *also = nullptr;
     const double *s0 = nullptr, *s1 = nullptr;
+    int kind = 0;
+    const double *part = nullptr;   // partials of the producing kernel
+    int np = 0;
+    const PcgS *in = nullptr;
+    PcgS *out = nullptr;
+    double eps10 = 0.0;             // 10 eps(T)
+    int f32 = 1;                    // the solver's element type is Float32 (scalars are rounded to it)
+    int also_x = 0;                 // run also when only the deferred x update is owed (direction kernel)
 };
 struct Pre { int act; double s0, s1; };
+// pcg!'s scalar logic, shared by the in-kernel form (gate_open) and the k_finalize epilogues of op_pcg
+__device__ __forceinline__ double pcg_rnd(double x, int f32) { return f32 ? (double)(float)x : x; }
+__device__ __forceinline__ double pcg_div(double a, double b, int f32) { return f32 ? (double)((float)a / (float)b) : a / b; }
+__device__ __forceinline__ void pcg_after_init(PcgS &s, double v, double eps10, int f32) {
+    const double rho = pcg_rnd(v, f32);
+    s.rho = rho; s.alpha = 0.0; s.beta = 0.0; s.r2 = 0.0;
+    s.nupd = 0; s.r2_valid = 0; s.xpend = 0;
+    s.active = !((rho < 0 ? -rho : rho) < eps10);
+}
+__device__ __forceinline__ void pcg_after_mult(PcgS &s, double v, int f32) {
+    s.xpend = 0;   // any owed x update was applied by the direction kernel before this mult
+    if (!s.active) return;
+    const double alpha = pcg_div(s.rho, pcg_rnd(v, f32), f32);
+    const double aa = alpha < 0 ? -alpha : alpha;
+    s.alpha = alpha;
+    if (aa < 1e-2 || aa > 1e2) s.active = 0;   // :132
+}
+__device__ __forceinline__ void pcg_after_update(PcgS &s, double v, double eps10, int f32, bool xnow) {   // non-final iteration
+    if (!s.active) return;
+    s.nupd += 1;
+    const double rho2 = pcg_rnd(v, f32);
+    if ((rho2 < 0 ? -rho2 : rho2) < eps10) { s.active = 0; s.xpend = !xnow; return; }   // :138
+    s.beta = pcg_div(rho2, s.rho, f32);
+    s.rho = rho2;
+}
+// sum of np partials, same order as k_finalize; 256-thread workgroups, every thread must call; all threads get the value
+__device__ __forceinline__ double block_sum_partials(const double *part, int np) {
+    __shared__ double bc;
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < np; i += 256) acc[0] = acc[0] + part[i];
+    block_red<1>(acc, RED_SUM);
+    if (threadIdx.x == 0) bc = acc[0];
+    __syncthreads();
+    return bc;
+}
 __device__ __forceinline__ bool gate_open(const Gate &gt, Pre &pre) {
     pre.act = 1; pre.s0 = 0.0; pre.s1 = 0.0;
     bool run = true;
-    if (gt.active) { pre.act = *gt.active; run = pre.act || (gt.also && *gt.also); }
-    if (gt.s0) pre.s0 = *gt.s0;
-    if (gt.s1) pre.s1 = *gt.s1;
-    return run;
+    if (gt.kind == 0) {
+        if (gt.active) { pre.act = *gt.active; run = pre.act || (gt.also && *gt.also); }
+        if (gt.s0) pre.s0 = *gt.s0;
+        if (gt.s1) pre.s1 = *gt.s1;
+        return run;
+    }
+    PcgS s;
+    if (gt.kind == 1) {
+        pcg_after_init(s, block_sum_partials(gt.part, gt.np), gt.eps10, gt.f32);
+    } else {
+        s = *gt.in;
+        if (gt.kind == 2) pcg_after_mult(s, block_sum_partials(gt.part, gt.np), gt.f32);
+        else if (gt.kind == 3) pcg_after_update(s, block_sum_partials(gt.part, gt.np), gt.eps10, gt.f32, false);
+    }
+    if (gt.out && blockIdx.x == 0 && threadIdx.x == 0) *gt.out = s;
+    pre.act = s.active; pre.s0 = s.alpha; pre.s1 = s.beta;
+    return s.active || (gt.also_x && s.xpend);
 }
 
 // ---- stencil operand sources: vec(o,i,j,k) = the V cells starting at (i,j,k) [offset o], scal = one cell
