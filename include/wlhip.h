@@ -235,6 +235,8 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  *        pass less per iteration, identical values), 0 = in the update kernel as the reference orders it
  * key 9: 1 = the 7-point kernels skip the loads of L in rows whose face coefficients are all one number (rows clear
  *        of the body and the domain faces; constants recorded by wl_mg_update) (default), 0 = always load L
+ * key 10: 1 = inside solver! the start of pcg! (eps = r*iD, rho) is evaluated by the prolongate!+increment! kernel that
+ *         has just produced r (default), 0 = by pcg!'s own first kernel
  * key 13: 1 = pcg! does not store z' = r*iD, the direction kernel recomputes it (default), 0 = stored as in the reference
  * key 15: 1 = on levels of at most 2^25 cells pcg!'s dot products are finished by the kernel that follows (no
  *         one-workgroup finalize launches inside a pcg! call; single rank) (default), 2 = on every level, 0 = separate

@@ -272,7 +272,9 @@ template <class T, int D> static int mg_update(wl_mg *m) {
 }
 
 // Vcycle!  src/MultiLevelPoisson.jl:70-82
-template <class T, int D> static int mg_vcycle(wl_mg *m, int l) {
+// pcg_np (solver! only): receives the partial count when the closing prolongate!+increment! also did the start of the
+// pcg! that the caller runs next on level l (eps = r*iD, rho partials), else -1
+template <class T, int D> static int mg_vcycle(wl_mg *m, int l, int *pcg_np = nullptr) {
     LevelT<T> fine = lvl<T>(m, l), coarse = lvl<T>(m, l + 1);
     const bool fused = (m->permask == 0) && ctx().opt[1];   // periodic ghosts of eps are copies, not zeros: keep the two-pass form
     if (fused) WL_TRY((op_smooth_fused<T, D>(fine, fine.eps)));     // r' lives in the eps buffer until the way up
@@ -304,10 +306,12 @@ template <class T, int D> static int mg_vcycle(wl_mg *m, int l) {
         }
     }
     if (!tail) {
-        if (l + 2 < m->nlev) WL_TRY((mg_vcycle<T, D>(m, l + 1)));
-        WL_TRY((op_pcg<T, D>(coarse, 6, m->permask, m->sc.partials, m->sc.st, false, (T *)m->scr[l + 1])));
+        int pre = -1;
+        if (l + 2 < m->nlev) WL_TRY((mg_vcycle<T, D>(m, l + 1, pcg_np ? &pre : nullptr)));
+        WL_TRY((op_pcg<T, D>(coarse, 6, m->permask, m->sc.partials, m->sc.st, false, (T *)m->scr[l + 1], pre)));
     }
-    if (fused) return op_prolong_increment_fused<T, D>(fine, fine.eps, coarse.g, coarse.x);
+    if (pcg_np) *pcg_np = -1;
+    if (fused) return op_prolong_increment_fused<T, D>(fine, fine.eps, coarse.g, coarse.x, m->sc.partials, pcg_np);
     WL_TRY((op_prolongate<T, D>(fine.g, fine.eps, coarse.g, coarse.x)));
     return op_increment<T, D>(fine, m->permask);
 }
@@ -319,8 +323,9 @@ template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, in
     WL_TRY((op_residual<T, D>(p, m->permask, m->sc.partials, m->sc.st)));
     int n = 0;
     while (n < itmx) {
-        if (m->nlev > 1) WL_TRY((mg_vcycle<T, D>(m, 0)));
-        WL_TRY((op_pcg<T, D>(p, 6, m->permask, m->sc.partials, m->sc.st, true, (T *)m->scr[0])));
+        int pre = -1;
+        if (m->nlev > 1) WL_TRY((mg_vcycle<T, D>(m, 0, &pre)));
+        WL_TRY((op_pcg<T, D>(p, 6, m->permask, m->sc.partials, m->sc.st, true, (T *)m->scr[0], pre)));
         WL_TRY((op_L2<T, D>(p, m->sc.partials, m->sc.st, true)));
         WL_TRY(m->sc.fetch());
         ++n;

@@ -732,8 +732,9 @@ int op_residual(const LevelT<T> &p, int permask, double *partials, State *st) {
         if (stencil7_ok<T>(p.g, p.x, p.L) && stencil7_ok<T>(p.g, p.r, p.iD) && stencil7_ok<T>(p.g, p.z, p.L)) {
             using VA = VecA<T>;
             exchanged = true;
-            rcv = launch_stencil7_halo<T, 1>(WL_K_RESIDUAL, p.g, p.x, SrcArray<T>{p.x}, p.L, p.rowc, p.iD, p.z,
-                [=] __device__(long o, const VA &ax, const VA &, const VA &id, const VA &zz, double *acc, const Pre &) {
+            rcv = launch_stencil7_halo<T, 1>(WL_K_RESIDUAL, p.g, p.x, SrcArray<T>{p.x}, p.L, p.rowc, (const T *)nullptr, p.z,
+                [=] __device__(long o, int j, int k, const VA &ax, const VA &, const VA &, const VA &zz, double *acc, const Pre &) {
+                const VA id = load_iD<T>(q.iD, q.rowc, q.g.n[0], q.g.n[1], o, (int)(o - q.g.s[1] * j - q.g.s[2] * k), j, k);
                 VA rv;
 _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) {
@@ -778,7 +779,7 @@ int op_increment(const LevelT<T> &p, int permask) {
             using VA = VecA<T>;
             exchanged = true;
             const int rcv = launch_stencil7_halo<T, 0>(WL_K_INCREMENT, p.g, p.eps, SrcArray<T>{p.eps}, p.L, p.rowc, p.r, p.x,
-                [=] __device__(long o, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
+                [=] __device__(long o, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
                 VA rv = r0, xv = x0;
 _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
@@ -825,7 +826,7 @@ int op_smooth_fused(const LevelT<T> &p, T *rout) {
             using VA = VecA<T>;
             exchanged = true;
             const int rcv = launch_stencil7_halo<T, 0>(WL_K_SMOOTH, p.g, p.r, SrcJacobi<T>{p.r, p.iD, p.rowc, p.g.n[0], p.g.n[1]}, p.L, p.rowc,
-                p.r, p.x, [=] __device__(long o, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
+                p.r, p.x, [=] __device__(long o, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
                     VA rv = r0, xv = x0;
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
@@ -858,17 +859,46 @@ _Pragma("unroll")
 // prolongate!(fine.eps, coarse.x) ; increment!(fine)  (src/MultiLevelPoisson.jl:80-81) in ONE pass: eps at a
 // fine cell is the coarse x of its parent (down(I), :2), 0 on ghost cells; residual read from `rin`, written to
 // p.r (the pair of fused kernels moves r: R -> E -> R, so the buffers end up in their own roles).
+// pcg_np (optional, solver! only): the pcg! call that follows on this level starts with eps = r*iD, rho = r.eps
+// (Poisson.jl:125-126) -- one more pass over the r this kernel has just computed.  When pcg_np is given (and the level
+// takes the vector kernel) that start is done HERE: eps (into p.eps, which is `rin`'s buffer: each thread overwrites
+// only the element it has already read) and the partials of rho (into `partials`); *pcg_np = their count, else -1.
 template <class T, int D>
-int op_prolong_increment_fused(const LevelT<T> &p, const T *rin, const G &gc, const T *cx) {
+int op_prolong_increment_fused(const LevelT<T> &p, const T *rin, const G &gc, const T *cx, double *partials = nullptr,
+                               int *pcg_np = nullptr) {
     WL_TRY((halo_exchange<T>(gc, const_cast<T *>(cx), 1, 1)));   // z-slab coarse level: parents in the halo plane
     const LevelT<T> q = p;
     const G C = gc;
+    if (pcg_np) *pcg_np = -1;
     if constexpr (D == 3) {
         if (stencil7_ok<T>(p.g, p.r, p.L) && stencil7_ok<T>(p.g, rin, p.x)) {
             using VA = VecA<T>;
             const SrcProlong<T> src{cx, C, p.g.n[0], p.g.n[1], p.g.nzg, p.g.kz0};
+            if (pcg_np && partials && ctx().opt[10] && ctx().opt[13] && ctx().opt[5] == 2 && !ctx().opt[4] && stencil7_ok<T>(p.g, p.eps, p.iD)) {
+                T *e0 = p.eps;
+                const int tpp = (((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 3) / 4) + 7) / 8 * 8;
+                const int keep = ctx().opt[11];
+                if (tpp <= 1024) ctx().opt[11] = 1024 / tpp;   // few partials: pcg!'s first mult kernel may sum them itself
+                int np = 0;
+                const int rcv = launch_stencil7ab<T, 1>(WL_K_SMOOTH, p.g, src, p.L, p.rowc, rin, p.x,
+                    [=] __device__(long o, int j, int k, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *acc, const Pre &) {
+                        VA rv = r0, xv = x0;
+                        const VA id = load_iD<T>(q.iD, q.rowc, q.g.n[0], q.g.n[1], o, (int)(o - q.g.s[1] * j - q.g.s[2] * k), j, k);
+_Pragma("unroll")
+                        for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
+                        rv.store(q.r + o);
+                        xv.store(q.x + o);
+                        VA ev;
+_Pragma("unroll")
+                        for (int v = 0; v < VA::V; ++v) { ev.v[v] = rv.v[v] * id.v[v]; acc[0] += (double)rv.v[v] * (double)ev.v[v]; }
+                        ev.store(e0 + o);
+                    }, partials, &np);
+                ctx().opt[11] = keep;
+                if (rcv > 0) return rcv;
+                if (rcv == 0) { *pcg_np = np; return 0; }
+            }
             const int rcv = launch_stencil7ab<T, 0>(WL_K_SMOOTH, p.g, src, p.L, p.rowc, rin, p.x,
-                [=] __device__(long o, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
+                [=] __device__(long o, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
                     VA rv = r0, xv = x0;
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
@@ -916,7 +946,8 @@ _Pragma("unroll")
 // evaluated on the fly at the 7 stencil points and written out of place (eps <-> scratch ping-pong), z = r*iD is never
 // stored: 15T instead of 16T per iteration and one launch fewer; per-cell arithmetic unchanged.
 template <class T, int D>
-int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st, bool want_r2 = false, T *scratch = nullptr) {
+int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st, bool want_r2 = false, T *scratch = nullptr,
+           int pre_np = -1) {   // pre_np >= 0: eps = r*iD and the partials of rho are already there (op_prolong_increment_fused)
     const LevelT<T> q = p;
     const Range R = r_inside(p.g);
     const T eps10 = (T)10 * Lim<T>::eps;
@@ -953,7 +984,8 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     int np0 = 0, npA = 0, cur = 0;   // cur: the slot holding the current state
     // :125-127
     int rv0 = -1;
-    if (vec) {
+    if (pre_np >= 0) { rv0 = 0; np = np0 = pre_np; }
+    else if (vec) {
         rv0 = launch_rowvec<T, 1>(WL_K_PCG_INIT, p.g, [=] __device__(long o, int j, int k, double *acc, const Pre &pre) {
             const VA rr = VA::load(q.r + o);
             const VA id = load_iD<T>(q.iD, q.rowc, q.g.n[0], q.g.n[1], o, (int)(o - q.g.s[1] * j - q.g.s[2] * k), j, k);
@@ -999,7 +1031,7 @@ _Pragma("unroll")
                     const T *eold = ecur;
                     rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g,
                         SrcDirection<T>{ecur, p.r, p.iD, p.rowc, p.g.n[0], p.g.n[1], (T)0}, p.L, p.rowc,
-                        [=] __device__(long o, const VA &ae, const VA &ec, double *acc, const Pre &pre) {
+                        [=] __device__(long o, int, int, const VA &ae, const VA &ec, double *acc, const Pre &pre) {
                             if (xdef) {
                                 const T alpha = (T)pre.s0;
                                 const VA ev = VA::load(eold + o);
@@ -1024,7 +1056,7 @@ _Pragma("unroll")
                 else { gate_mult.kind = 4; gate_mult.in = &st->slots[cur]; }
                 gate_mult.eps10 = (double)eps10; gate_mult.f32 = f32;
                 rcv = launch_stencil7_halo<T, 1>(WL_K_PCG_MULT, p.g, ecur, SrcArray<T>{esrc}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
-                    [=] __device__(long o, const VA &ae, const VA &ec, const VA &, const VA &, double *acc, const Pre &) {
+                    [=] __device__(long o, int, int, const VA &ae, const VA &ec, const VA &, const VA &, double *acc, const Pre &) {
                     ae.store(q.z + o);
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];

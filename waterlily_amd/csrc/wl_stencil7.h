@@ -13,7 +13,7 @@
 //     the same number c (1 on the finest level, 2^l below: restrictL! sums four unit faces and halves).  wl_mg_update
 //     records c per row (NaN = not uniform, see k_lrow); in such a row the kernel does not load L at all (3 of the 5
 //     array passes of mult) and uses c -- the very values the loads would have returned, so results are unchanged;
-//   * an epilogue functor turns A e into the operator at hand: z=Ae & z.e (pcg!), r-=Ae & x+=e (increment!),
+//   * an epilogue functor epi(o, j, k, Ae, e, acc, pre) turns A e into the operator at hand: z=Ae & z.e (pcg!), r-=Ae & x+=e (increment!),
 //     r = z-Ax (residual!), with per-thread Float64 partials reduced exactly like the range kernels.
 // Per-cell arithmetic and its order are those of mult()/set_diag! => bit-identical to the generic kernels.
 // Requirements (else the caller falls back to the generic range kernel): D==3 and (n0-2) % V == 0.
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__r
                 s += em.v[v] * lzc.v[v] + ep.v[v] * lzp.v[v];
                 ae.v[v] = s;
             }
-            epi(o, ae, ec, acc, pre);
+            epi(o, j, k, ae, ec, acc, pre);
             em = ec; ec = ep; ep = en; lzc = lzp;
         }
     }
@@ -467,7 +467,7 @@ inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, const T 
     if (ctx().opt[4]) return launch_stencil7_by<T, NRED, 8>(kclass, g, src, L, rowc, epi, partials, np, gate, kov_lo, kov_hi);
     return launch_stencil7_by<T, NRED, 4>(kclass, g, src, L, rowc, epi, partials, np, gate, kov_lo, kov_hi);
 }
-// Launch with two epilogue operand arrays: EPI(o, Ae, e, a, b, acc, pre) receives the V values of ea and eb at o
+// Launch with two epilogue operand arrays: EPI(o, j, k, Ae, e, a, b, acc, pre) receives the V values of ea and eb at o
 // (e.g. r and x of increment!), loaded next to the stencil operands.  (A software-pipelined variant of the kernel --
 // loads of plane k+1/k+2 issued one iteration ahead, sources split into load/arithmetic halves -- was measured at
 // 512^3 and 256^3: no gain, 124-152 VGPRs; the kernels are not latency-bound.  See DESIGN.md.)
@@ -476,11 +476,11 @@ inline int launch_stencil7ab(int kclass, const G &g, SRC src, const T *L, const 
                              double *partials, int *np, Gate gate = Gate(), int kov_lo = 0, int kov_hi = -1) {
     using VA = VecA<T>;
     return launch_stencil7<T, NRED>(kclass, g, src, L, rowc,
-        [=] __device__(long o, const VA &ae, const VA &ec, double *acc, const Pre &pre) {
+        [=] __device__(long o, int j, int k, const VA &ae, const VA &ec, double *acc, const Pre &pre) {
             VA a = ec, b = ec;
             if (ea) a = VA::load(ea + o);
             if (eb) b = VA::load(eb + o);
-            epi(o, ae, ec, a, b, acc, pre);
+            epi(o, j, k, ae, ec, a, b, acc, pre);
         }, partials, np, gate, kov_lo, kov_hi);
 }
 
