@@ -13,6 +13,7 @@ Closure convention: ``sdf(x, t)`` and ``map(x, t)`` receive ``x`` as a float64 t
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Optional, Sequence, Tuple
 
 import numpy as np
@@ -72,9 +73,13 @@ def _as_points(x) -> Tuple[torch.Tensor, bool]:
     return (x[:, None] if single else x), single
 
 
-def sdf(body: AutoBody, x, t=0.0) -> torch.Tensor:
-    """AutoBody.jl:38"""
-    xp, single = _as_points(x)
+def sdf(body: AutoBody, x, t=0.0, keep_dtype=False) -> torch.Tensor:
+    """AutoBody.jl:38.  keep_dtype: evaluate in the dtype of the tensor `x` (the reference evaluates sdf(loc(0,I,T)) in
+    the field type T, Body.jl:34) instead of Float64."""
+    if keep_dtype and isinstance(x, torch.Tensor) and x.is_floating_point():
+        xp, single = (x[:, None] if x.ndim == 1 else x), x.ndim == 1
+    else:
+        xp, single = _as_points(x)
     d = body.sdf(xp, torch.as_tensor(float(t), dtype=torch.float64, device=xp.device))
     d = torch.broadcast_to(d, (xp.shape[1],))
     return d[0] if single else d
@@ -169,11 +174,11 @@ def _mu1_t(d, eps):
 _TT = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
 
 
-def _chunk_points(Ng, lo, hi, device):
+def _chunk_points(Ng, lo, hi, device, dtype=torch.float64):
     """cell centres loc(0,I) (util.jl:160) of the INTERIOR cells with global last index in [lo,hi):
-    returns (points (D, M) float64, shape of the chunk)"""
-    ax = [torch.arange(1, n - 1, dtype=torch.float64, device=device) - 0.5 for n in Ng[:-1]]
-    ax.append(torch.arange(lo, hi, dtype=torch.float64, device=device) - 0.5)
+    returns (points (D, M) of `dtype`, shape of the chunk).  (Half-integers: exact in Float32 up to 2^23.)"""
+    ax = [torch.arange(1, n - 1, dtype=dtype, device=device) - 0.5 for n in Ng[:-1]]
+    ax.append(torch.arange(lo, hi, dtype=dtype, device=device) - 0.5)
     g = torch.meshgrid(*ax, indexing="ij")
     shp = tuple(g[0].shape)
     return torch.stack([q.reshape(-1) for q in g]), shp
@@ -201,7 +206,7 @@ def measure_fields_into(body, dims: Sequence[int], mu0, mu1, V, dsdf, t: float =
     Ng = tuple(int(n) + 2 for n in dims)      # extents of the undecomposed array
     dev, tdt = mu0.device, mu0.dtype
     if chunk_cells is None:                    # big chunks on the GPU: few launches, few host syncs
-        chunk_cells = (1 << 25) if dev.type == "cuda" else (1 << 22)
+        chunk_cells = int(os.environ.get("WL_MEASURE_CHUNK", 1 << 28)) if dev.type == "cuda" else (1 << 22)   # 512^3 in one piece
     lstrides = [1]
     for n in mu0.shape[:D - 1]:
         lstrides.append(lstrides[-1] * int(n))
@@ -220,18 +225,25 @@ def measure_fields_into(body, dims: Sequence[int], mu0, mu1, V, dsdf, t: float =
     inner = tuple(slice(1, n - 1) for n in Ng[:-1])
     for lo in range(g_lo, g_hi, step):
         hi = min(g_hi, lo + step)
-        pts, shp = _chunk_points(Ng, lo, hi, dev)
-        dc = sdf(body, pts, t).to(tdt)                       # stored into sigma::T (Body.jl:34)
+        # the distance of every cell centre, evaluated in the field type T like the reference (Body.jl:34: sdf(loc(0,I,T)),
+        # stored into sigma::T) -- for Float32 fields half the bytes of a Float64 evaluation over the whole grid.  It
+        # only decides band membership (|d| < 2+eps, where mu0 = 1 and mu1 = V = 0 anyway) and inside/outside far from
+        # the surface; the band cells themselves are measured in Float64 below.
+        pts, shp = _chunk_points(Ng, lo, hi, dev, tdt)
+        dc = sdf(body, pts, t, keep_dtype=True).to(tdt)
         ksl = slice(lo - kz0, hi - kz0)
         dsdf[inner + (ksl,)] = dc.reshape(shp)
         band = (dc * dc) < torch.as_tensor(d2, dtype=tdt, device=dev)   # Body.jl:35, compared in T
         inside_body = (~band) & (dc < 0)
-        if bool(inside_body.any()):
-            sub = mu0[inner + (ksl,)]
-            sub[inside_body.reshape(shp)] = 0                # all D components of those cells
+        iidx = torch.nonzero(inside_body)[:, 0]             # cells inside the body, away from the surface: mu0 = 0
+        if iidx.numel():                                     # (scatter on the few such cells, not a masked pass over the field)
+            isub = list(torch.unravel_index(iidx, shp))
+            ifull = tuple(q + 1 for q in isub[:-1]) + (isub[-1] + (lo - kz0),)
+            for i in range(D):
+                mu0[ifull + (i,)] = 0
         if bool(band.any()):
             bidx = torch.nonzero(band)[:, 0]
-            xb = pts[:, bidx]
+            xb = pts[:, bidx].to(torch.float64)
             sub = list(torch.unravel_index(bidx, shp))
             full = tuple(s + 1 for s in sub[:-1]) + (sub[-1] + (lo - kz0),)
             cand.append(sum(f.to(torch.int64) * int(s) for f, s in zip(full, lstrides)))
