@@ -281,6 +281,34 @@ def measure_fields(body, dims: Sequence[int], t: float = 0.0, eps: float = 1.0, 
     return m0.numpy(), m1.numpy(), Vv.numpy(), dd.numpy()
 
 
+def nds_band_from_candidates(body, dims: Sequence[int], candidates: "torch.Tensor", t: float = 0.0, slab=None):
+    """nds_band restricted to `candidates` (LOCAL column-major linear indices, a superset of the |d| <= 1 band, on the
+    device where the closures shall run), everything kept on that device: returns (idx int64, nds (n, D) float64)
+    torch tensors sorted by idx -- no host round trip (measure!'s band cells -> pressure_force on the GPU)."""
+    D = len(dims)
+    Ng = tuple(int(n) + 2 for n in dims)
+    strides = np.cumprod((1,) + Ng[:-1])
+    dev = candidates.device
+    kz0c = slab.kz0 if slab is not None else 0
+    cand = candidates
+    if slab is not None:                       # owned interior planes only
+        kk = cand // int(strides[D - 1])
+        cand = cand[(kk >= slab.own_lo) & (kk <= slab.own_hi) & (kk + kz0c >= 1) & (kk + kz0c <= Ng[-1] - 2)]
+    if cand.numel() == 0:
+        return torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros((0, D), dtype=torch.float64, device=dev)
+    rem, coords = cand.clone(), []
+    for ddim in range(D - 1, -1, -1):
+        coords.insert(0, rem // int(strides[ddim]))
+        rem = rem % int(strides[ddim])
+    pts = torch.stack([c.to(torch.float64) - 0.5 for c in coords])
+    pts[D - 1] += kz0c
+    d, n, _ = measure(body, pts, t, fastd2=1.0)
+    v = (n * _kern_t(torch.clamp(d, -1, 1))[None]).T
+    keep = (v != 0).any(1)
+    idx, order = torch.sort(cand[keep], stable=True)
+    return idx, v[keep][order].contiguous()
+
+
 def nds_band(body, dims: Sequence[int], t: float = 0.0, chunk_cells: Optional[int] = None, slab=None, device="cpu",
              candidates=None):
     """Metrics.jl:84-87 evaluated over inside(p): returns (idx, nds) where idx are the column-major
@@ -297,25 +325,8 @@ def nds_band(body, dims: Sequence[int], t: float = 0.0, chunk_cells: Optional[in
     if chunk_cells is None:
         chunk_cells = (1 << 25) if torch.device(device).type == "cuda" else (1 << 22)
     if candidates is not None:
-        kz0c = slab.kz0 if slab is not None else 0
-        cand = candidates.to(device)
-        if slab is not None:                       # owned interior planes only
-            kk = cand // int(strides[D - 1])
-            cand = cand[(kk >= slab.own_lo) & (kk <= slab.own_hi) & (kk + kz0c >= 1) & (kk + kz0c <= Ng[-1] - 2)]
-        if cand.numel() == 0:
-            return np.zeros(0, dtype=np.int64), np.zeros((0, D))
-        rem, coords = cand.clone(), []
-        for ddim in range(D - 1, -1, -1):
-            coords.insert(0, rem // int(strides[ddim]))
-            rem = rem % int(strides[ddim])
-        pts = torch.stack([c.to(torch.float64) - 0.5 for c in coords])
-        pts[D - 1] += kz0c
-        d, n, _ = measure(body, pts, t, fastd2=1.0)
-        v = (n * _kern_t(torch.clamp(d, -1, 1))[None]).T
-        keep = (v != 0).any(1)
-        idx, nds = cand[keep].cpu().numpy(), v[keep].cpu().numpy()
-        order = np.argsort(idx, kind="stable")
-        return idx[order], np.ascontiguousarray(nds[order])
+        idx_t, nds_t = nds_band_from_candidates(body, dims, candidates.to(device), t=t, slab=slab)
+        return idx_t.cpu().numpy(), np.ascontiguousarray(nds_t.cpu().numpy())
     plane = int(np.prod(Ng[:-1]))
     step = max(1, chunk_cells // plane)
     idxs, vals = [], []

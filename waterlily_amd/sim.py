@@ -658,6 +658,7 @@ def measure(sim: Simulation, t=None) -> None:
 def sim_step(sim: Simulation, t_end=None, *, remeasure=True, max_steps=None, verbose=False) -> None:
     """WaterLily.jl:98-109"""
     if t_end is None:
+        sim._moving = bool(remeasure)          # remeasure=False: the body is declared static (see _ensure_band)
         if remeasure:
             measure(sim)
         mom_step(sim.flow, sim.pois)
@@ -746,9 +747,32 @@ def pressure_force(sim: Simulation) -> np.ndarray:
 
 
 def _ensure_band(sim: Simulation) -> None:
-    if sim._band is None or sim._band[0] != time(sim.flow):
-        bc = getattr(sim.flow, "_band_cells", None)
-        cand = bc[1] if (bc is not None and abs(bc[0] - time(sim.flow)) <= 1e-12 * max(1.0, abs(bc[0]))) else None
-        idx, nds = B.nds_band(sim.body, tuple(n - 2 for n in sim.flow.N), t=time(sim.flow), slab=sim.slab,
-                              device=sim.flow.device if sim.geometry == "device" else "cpu", candidates=cand)
-        sim._band = (time(sim.flow),) + band_to_device(sim.flow.p, idx, nds)
+    """The |d| <= 1 band (cell offsets + n*kern vectors, Metrics.jl:84-87) on the device.  The reference evaluates
+    nds(body, x, t) over the whole grid at every call; here it is rebuilt only when it can have changed: when the flow
+    time moved AND the body is being re-measured (sim_step(remeasure=True), a moving body).  With remeasure=False the
+    caller declares the body static -- the solver keeps using the coefficients of the last measure! -- and the band of
+    that measure! stays valid.  A rebuild examines only the cells of the last measure!'s band |d| < 2+eps (a body moves
+    less than a cell per step), on the device, without a host round trip."""
+    t = time(sim.flow)
+    if sim._band is not None and (sim._band[0] == t or not getattr(sim, "_moving", True)):
+        return
+    dims = tuple(n - 2 for n in sim.flow.N)
+    bc = getattr(sim.flow, "_band_cells", None)
+    if bc is not None and sim.geometry == "device":
+        idx, nds = B.nds_band_from_candidates(sim.body, dims, bc[1], t=t, slab=sim.slab)
+        sim._band = (t,) + band_to_device_t(sim.flow.p, idx, nds)
+        return
+    idx, nds = B.nds_band(sim.body, dims, t=t, slab=sim.slab,
+                          device=sim.flow.device if sim.geometry == "device" else "cpu")
+    sim._band = (t,) + band_to_device(sim.flow.p, idx, nds)
+
+
+def band_to_device_t(p: torch.Tensor, idx: torch.Tensor, nds: torch.Tensor):
+    """band_to_device for index / vector tensors that already live on p's device"""
+    off = torch.zeros_like(idx)
+    rem = idx.clone()
+    dense = np.cumprod((1,) + tuple(p.shape[:-1]))
+    for ddim in range(p.ndim - 1, -1, -1):
+        off += (rem // int(dense[ddim])) * int(p.stride()[ddim])
+        rem = rem % int(dense[ddim])
+    return off.contiguous(), nds.to(torch.float64).contiguous()
