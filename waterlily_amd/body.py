@@ -80,7 +80,9 @@ def sdf(body: AutoBody, x, t=0.0, keep_dtype=False) -> torch.Tensor:
         xp, single = (x[:, None] if x.ndim == 1 else x), x.ndim == 1
     else:
         xp, single = _as_points(x)
-    d = body.sdf(xp, torch.as_tensor(float(t), dtype=torch.float64, device=xp.device))
+    # (t in the points' dtype: the reference passes t::T (Body.jl:31), and a Float64 t would promote a map closure's
+    #  output -- and the whole evaluation -- to Float64)
+    d = body.sdf(xp, torch.as_tensor(float(t), dtype=xp.dtype, device=xp.device))
     d = torch.broadcast_to(d, (xp.shape[1],))
     return d[0] if single else d
 
