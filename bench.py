@@ -153,6 +153,7 @@ def main():
     L = _lib.lib()
     T = np.float32 if args.dtype == "f32" else np.float64
     tsz = np.dtype(T).itemsize
+    transport = "rccl" if args.comm == "rccl" else "host staging over gloo"
     if args.comm == "host":
         local = local % max(1, torch.cuda.device_count())
     dev = f"cuda:{local}"
@@ -160,7 +161,19 @@ def main():
     if world > 1 and args.comm == "rccl":
         # one process per GPU; the z axis is cut into `world` slabs, halos + scalar all-reduces run over RCCL (xGMI)
         dist.init_process_group("nccl", device_id=torch.device(dev))
-        wd.init_rccl()
+        ok = 1
+        try:
+            wd.init_rccl()
+        except Exception as e:   # e.g. ncclCommInitRank refused: fall back to host staging over gloo rather than no number
+            print(f"[bench] rank {rank}: RCCL communicator failed ({e}); falling back to --comm host", file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if ok:
+                wd.finalize()
+            wd.init_host(dist.new_group(backend="gloo"))
+            transport = "host staging over gloo (RCCL fallback)"
     elif world > 1:
         dist.init_process_group("gloo")
         wd.init_host()
@@ -254,7 +267,7 @@ def main():
         "config": {"workload": f"3D {args.body} {dims[0]}x{dims[1]}x{dims[2]}, Re={3700 if args.body == 'sphere' else 1000}, {args.dtype}, uniform inflow, "
                                f"remeasure=false" + (", dense layout" if args.layout == "dense" else "") + (" (BASELINE configs[2])" if world == 1 and not args.grid and m == 512
                                                      and args.dtype == "f32" and args.body == "sphere" else "" if world == 1 else
-                                                     f", z-slabs over {world} GPUs (RCCL halo exchange)"),
+                                                     f", z-slabs over {world} GPUs ({transport})"),
                    "vcycles_per_solve": vcycles[:6], "mean_vcycles_per_step": float(np.sum(vcycles)) / args.steps},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": nl.value,
