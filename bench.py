@@ -4,9 +4,22 @@
     python bench.py --gpus 1 --steps K --warmup W
 
 One "step" = one `sim_step!(sim; remeasure=false)` = one `mom_step!` (predictor + corrector, both pressure
-solves, CFL).  Workload at N=1: BASELINE.json configs[2], the configuration the metric is quoted on:
+solves, CFL).  Workload at N=1: BASELINE.json configs[2] (C3), the configuration the metric is quoted on:
 3-D sphere, 512^3, Float32, Re=3700, uniform inflow (geometry as README.md:118-125 of the reference).
 Inputs are synthetic and resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+
+JSON extras:
+  roofline      the kernel class that takes most of a step (hipEvents on the library's stream inside the timed region):
+                `achieved` = the bytes the kernel HAS TO move per launch (its own operator's compulsory traffic: every
+                distinct array element it needs read once + written once; coefficient arrays are not needed in
+                coefficient-uniform rows, D is recomputed -- DESIGN.md section 4) / average launch duration, so frac <= 1
+                by construction; `dense` = the same with SURVEY 8(d)'s dense per-cell figure of the reference operator
+                (secondary: can exceed the peak, the kernel does not move those bytes); `traffic` = HBM bytes per launch
+                measured with rocprofv3 PMC counters for the SAME launch mix (profiles/traffic.json, see profiles/parse_pmc.py)
+  smoother      the same three figures for the V-cycle smoother Jacobi!+increment! (the north-star's >=40 % kernel) and
+  prolong_increment   for the fused prolongate!+increment! kernel, each on its own (finest level only)
+  cpu_baseline  the CPU restatement of the reference (oracle/, OpenMP) on BASELINE.md section 3's two CPU points:
+                C2 256^3 Float32 sphere (`value`) and C1 2-D circle 192x64 Float64 (`c1`)
 """
 from __future__ import annotations
 
@@ -27,32 +40,29 @@ os.environ.setdefault("OMP_PROC_BIND", "close")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s float4 copy)
 
-# ALGORITHMIC bytes per processed cell, in units of the element size T (each distinct array element the kernel's
-# operator reads once + writes once, dense -- SURVEY.md 8(d), DESIGN.md "kernels and their algorithmic bytes").
-# Keyed by libwlhip kernel class: (dense, never_moved, skipped_in_uniform_rows).  The kernels move LESS than `dense`:
-# `never_moved` is the diagonal D, recomputed from the six face coefficients; `skipped_in_uniform_rows` are the
-# coefficient arrays (L x3, iD) that are not loaded in x-rows whose coefficients are one number (rows clear of the
-# body: 94 % of the rows of the 512^3 sphere case).  roofline.achieved uses `dense` (the contract's figure, which can
-# therefore exceed the HBM peak); roofline.moved uses dense - never - phi*skipped, the bytes the kernel has to move.
+# Bytes per processed cell in units of the element size T, keyed by libwlhip kernel class:
+#   dense : SURVEY.md 8(d) -- every distinct array element of the REFERENCE operator read once + written once
+#   need  : what the fused kernel has to move in a coefficient-uniform x-row (row constants replace L and iD, D is
+#           recomputed from L): its own compulsory traffic
+#   extra : the additional arrays it has to load in a row that is NOT uniform (L x3, iD)
+# bytes it has to move per cell = need + (1 - phi) * extra, phi = share of coefficient-uniform rows (0.94 for the 512^3 sphere)
 ALG_T = {
-    "conv_diff": (10.5, 0, 0),         # fused conv_diff!+BDIM#1: u(3) [+u0(3) corrector] + V(3) -> f(3) [+u0(3) predictor]
-    "bdim": (22.5, 0, 0),              # BDIM#2: f(3) V(3) mu0(3) mu1(9) [+u(3) corrector] -> u(3): 21T/24T (dense)
-    "pcg_mult_dot": (6.0, 1, 3),       # eps, L(3), D -> z   (+ z.eps partial)
-    "pcg_update": (13.0 / 3, 0, 5.0 / 6),  # r, z, iD -> r (+ r.(r iD) partial): 4T; the 6th iteration x, eps, r, z -> x, r: 6T
-    "pcg_direction": (6.0, 0, 1),      # x, eps, r, iD -> x, eps   (x += alpha eps ; eps = beta eps + r iD)
-    "pcg_init": (3.0, 0, 1),           # r, iD -> eps
-    "smooth": (9.0, 1, 3.5),           # fused Jacobi!+increment! r,iD,x,D,L(3) -> r,x; fused prolongate!+increment! skips L only
-    "jacobi": (3.0, 0, 0),
-    "increment": (9.0, 1, 3),
-    "residual": (8.0, 1, 3),           # x, L(3), D, z, iD -> r
-    "restrict": (9.0, 0, 0),
-    "prolongate": (2.0, 0, 0),
-    "dot": (1.0, 0, 0),
-    "div": (4.0, 0, 0),
-    "correct": (10.0, 0, 0),           # u(3) rw, L(3), x
-    "scale": (2.0, 0, 0),
-    "cfl": (4.0, 0, 0),
-    "copy": (2.0, 0, 0),
+    #                  dense   need    extra
+    "conv_diff":      (12.0,   12.0,   0.0),   # u0.=u + conv_diff! + accelerate! + BDIM!#1: u(3),V(3) [+u0(3)] -> f(3) [+u0(3)]
+    "bdim":           (22.5,   7.5,    15.0),  # BDIM!#2: f(3) [+u(3)] -> u(3); busy rows also V(3), mu0(3), mu1(9)
+    "pcg_mult_dot":   (6.0,    2.0,    3.0),   # eps -> z (+ z.eps); L(3) in non-uniform rows; D recomputed
+    "pcg_update":     (13 / 3, 3.5,    5 / 6), # 5 of 6: r,z -> r (+ r.(r iD)); the 6th: x,eps,r,z -> x,r
+    "pcg_direction":  (6.0,    5.0,    1.0),   # x,eps,r -> x,eps
+    "pcg_init":       (3.0,    2.0,    1.0),   # r -> eps
+    "smooth":         (9.0,    4.0,    4.0),   # Jacobi!+increment!: r,x -> r,x ; iD, L(3) in non-uniform rows
+    "prolongate":     (9.125,  5.125,  4.0),   # prolongate!+increment! (+ start of pcg!): r,x,(coarse x) -> r,x,eps
+    "increment":      (9.0,    5.0,    3.0),
+    "residual":       (8.0,    3.0,    4.0),   # x,z -> r
+    "correct":        (10.0,   7.0,    3.0),   # u(3) rw, x ; L(3) in non-uniform rows
+    "div":            (4.0,    4.0,    0.0),
+    "cfl":            (4.0,    4.0,    0.0),
+    "scale":          (2.0,    2.0,    0.0),
+    "restrict":       (9.0,    9.0,    0.0),
 }
 
 
@@ -61,7 +71,7 @@ def sphere(dims, T, Re=3700.0, device="cuda:0", padded=True):
     sphere sits at the same x,y position and in the middle of the z extent)"""
     import torch
     from waterlily_amd import sim as S
-    from waterlily_amd.body import AutoBody, norm2
+    from waterlily_amd.body import AutoBody
     m = min(dims)
     radius = m / 8
     cx, cy, cz = m / 2 - 1, dims[1] / 2 - 1, dims[2] / 2 - 1
@@ -85,25 +95,34 @@ def donut(dims, T, Re=1000.0, device="cuda:0", padded=True):
     return S.Simulation(tuple(dims), (1.0, 0.0, 0.0), R, nu=R / Re, body=AutoBody(sdf), T=T, device=device, padded=padded)
 
 
-def cpu_baseline(size: int, steps: int):
-    """The CPU restatement of the reference (oracle/, OpenMP) timed on the host cores on a bounded sample."""
+def _cpu_case(dims, T, Re, steps):
+    """one CPU point: the oracle (oracle/wl_oracle.c, OpenMP; body measured by oracle/geometry.py) on the README's
+    circle / sphere case, `steps` steps after one warm-up step, remeasure=false"""
+    from oracle import geometry as G
     from oracle import wl_oracle as O
-    from waterlily_amd import body as B
-    from waterlily_amd.body import AutoBody, norm2
-    m = size
+    m = dims[-1]
     radius, center = m / 8, m / 2 - 1
-    body = AutoBody(lambda x, t: norm2(x - center) - radius)
-    s = O.Simulation((m, m, m), (1.0, 0.0, 0.0), 2 * radius, nu=2 * radius / 3700.0, body=body, T=np.float32,
-                     measure_fn=B.measure_fields, nds_fn=B.nds_band)
+    U = (1.0,) + (0.0,) * (len(dims) - 1)
+    s = O.Simulation(dims, U, 2 * radius, nu=2 * radius / Re, body=G.Body(G.Sphere(center, radius)), T=T)
     O.sim_step(s, remeasure=False)  # warm-up
     t0 = time.perf_counter()
     for _ in range(steps):
         O.sim_step(s, remeasure=False)
     dt = time.perf_counter() - t0
+    return int(np.prod(dims)) * steps / dt / 1e6, s.pois.n[-2:], dt
+
+
+def cpu_baseline(size: int, steps: int, c1_steps: int):
+    """C2 (3-D sphere 256^3 Float32 Re=3700) and C1 (2-D circle 192x64 Float64 Re=100)."""
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": m ** 3 * steps / dt / 1e6, "unit": "MLUPS", "cores": cores, "kind": "port",
-            "sample": f"{m}^3 sphere Re=3700 f32, {steps} steps after 1 warm-up, remeasure=false, "
-                      f"V-cycles/step={s.pois.n[-2:]}"}
+    v2, n2, t2 = _cpu_case((size,) * 3, np.float32, 3700.0, steps)
+    v1, n1, t1 = _cpu_case((192, 64), np.float64, 100.0, c1_steps)
+    return {"value": v2, "unit": "MLUPS", "cores": cores, "kind": "port",
+            "sample": f"C2: {size}^3 sphere Re=3700 f32, {steps} steps after 1 warm-up ({t2:.1f} s), remeasure=false, "
+                      f"V-cycles/step={n2}",
+            "c1": {"value": v1, "unit": "MLUPS", "cores": cores,
+                   "sample": f"C1: 2-D circle 192x64 Re=100 f64, {c1_steps} steps after 1 warm-up ({t1:.2f} s), "
+                             f"remeasure=false, V-cycles/step={n1}"}}
 
 
 def class_table(L):
@@ -125,15 +144,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512, help="cells per side (BASELINE config: 512)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--cpu-size", type=int, default=192)
-    ap.add_argument("--cpu-steps", type=int, default=30, help="timed steps of the CPU baseline (192^3: about 10 s on 16 cores)")
+    ap.add_argument("--cpu-size", type=int, default=256, help="C2 of BASELINE.md section 3")
+    ap.add_argument("--cpu-steps", type=int, default=8, help="timed steps of the C2 CPU baseline (256^3: about 0.5 s per step on 16 cores)")
+    ap.add_argument("--cpu-c1-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--body", default="sphere", choices=["sphere", "donut"], help="donut: BASELINE configs[4] (use with --dtype f64)")
     ap.add_argument("--layout", default="padded", choices=["padded", "dense"],
                     help="padded: rows 128-B aligned (default); dense: the reference's column-major layout (pitch N+2)")
     ap.add_argument("--kernel", default=None, help="force the kernel class reported in `roofline`")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "host"],
-                    help="multi-rank transport: rccl (one GPU per rank) or host (gloo staging; lets ranks share a GPU, tests)")
+                    help="multi-rank transport: rccl (one GPU per rank; a failing communicator is a non-zero exit) or host "
+                         "(explicit: gloo staging; lets ranks share a GPU, tests -- never an xGMI number)")
     ap.add_argument("--grid", type=int, nargs=3, default=None,
                     help="explicit GLOBAL grid nx ny nz (strong scaling, e.g. 1024 1024 512 = BASELINE configs[3])")
     args = ap.parse_args()
@@ -153,30 +174,28 @@ def main():
     L = _lib.lib()
     T = np.float32 if args.dtype == "f32" else np.float64
     tsz = np.dtype(T).itemsize
-    transport = "rccl" if args.comm == "rccl" else "host staging over gloo"
+    transport = "none" if world == 1 else ("rccl" if args.comm == "rccl" else "host-staging(gloo)")
     if args.comm == "host":
         local = local % max(1, torch.cuda.device_count())
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
     if world > 1 and args.comm == "rccl":
-        # one process per GPU; the z axis is cut into `world` slabs, halos + scalar all-reduces run over RCCL (xGMI)
+        # one process per GPU; the z axis is cut into `world` slabs, halos + scalar all-reduces run over RCCL (xGMI).
+        # A communicator that cannot be created is a failed run (non-zero exit with the library's error text): a number
+        # produced over any other transport would not be an xGMI measurement.
         dist.init_process_group("nccl", device_id=torch.device(dev))
-        ok = 1
         try:
             wd.init_rccl()
-        except Exception as e:   # e.g. ncclCommInitRank refused: fall back to host staging over gloo rather than no number
-            print(f"[bench] rank {rank}: RCCL communicator failed ({e}); falling back to --comm host", file=sys.stderr, flush=True)
-            ok = 0
-        flag = torch.tensor([ok], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if ok:
-                wd.finalize()
-            wd.init_host(dist.new_group(backend="gloo"))
-            transport = "host staging over gloo (RCCL fallback)"
+        except Exception as e:
+            print(f"[bench] rank {rank}: RCCL communicator failed: {e} | {L.wl_last_error().decode()}", file=sys.stderr, flush=True)
+            os._exit(3)   # (peers blocked inside ncclCommInitRank are torn down by the launcher)
     elif world > 1:
         dist.init_process_group("gloo")
         wd.init_host()
+    cr, cn = C.c_int(), C.c_int()
+    _lib.check(L.wl_comm_rank(C.byref(cr), C.byref(cn)))
+    if cn.value != world:
+        raise SystemExit(f"libwlhip communicator has {cn.value} ranks, launcher has {world}")
     m = args.size
     # N=1: the BASELINE 512^3 cube.  N>1 (default): WEAK scaling -- every GPU keeps a 512x512x512 slab, i.e. the
     # global grid is 512 x 512 x 512N; --grid gives an explicit global grid instead (strong scaling).
@@ -192,24 +211,24 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # warm-up; the last warm-up step times EVERY finest-level launch with hipEvents to find the dominant kernel
-    per_class = {}
+    def timed_class(nm):
+        """one extra step with every finest-level launch of class nm bracketed by hipEvents"""
+        _lib.check(L.wl_prof_reset())
+        _lib.check(L.wl_prof_select(names[nm], int(0.9 * ncell)))
+        S.sim_step(sim, remeasure=False)
+        nl, nc, ms = C.c_int64(), C.c_int64(), C.c_double()
+        _lib.check(L.wl_prof_timed(C.byref(nl), C.byref(nc), C.byref(ms)))
+        _lib.check(L.wl_prof_select(-1, 0))
+        return {"launches": nl.value, "ms": ms.value, "cells": nc.value}
+
     for w in range(args.warmup):
         S.sim_step(sim, remeasure=False)
     sync()
-    # each heavy finest-level class is timed with hipEvents in one extra warm-up step to find the dominant kernel
-    heavy = ["pcg_mult_dot", "pcg_update", "pcg_direction", "smooth", "conv_diff", "bdim", "residual"]
-    if args.kernel:
-        dominant = args.kernel
-    else:
-        for nm in heavy:
-            _lib.check(L.wl_prof_reset())
-            _lib.check(L.wl_prof_select(names[nm], int(0.9 * ncell)))
-            S.sim_step(sim, remeasure=False)
-            nl, nc, ms = C.c_int64(), C.c_int64(), C.c_double()
-            _lib.check(L.wl_prof_timed(C.byref(nl), C.byref(nc), C.byref(ms)))
-            per_class[nm] = {"launches": nl.value, "ms": ms.value}
-        dominant = max(per_class, key=lambda k: per_class[k]["ms"])
+    # each finest-level class is timed in one extra warm-up step: finds the dominant kernel, feeds the smoother objects
+    classes = ["pcg_mult_dot", "pcg_update", "pcg_direction", "smooth", "prolongate", "conv_diff", "bdim", "residual", "correct",
+               "div", "cfl", "scale"]
+    per_class = {nm: timed_class(nm) for nm in classes if nm in names}
+    dominant = args.kernel or max(per_class, key=lambda k: per_class[k]["ms"])
 
     # timed region: only the dominant class is bracketed by hipEvents (on the library's stream)
     _lib.check(L.wl_prof_reset())
@@ -231,35 +250,41 @@ def main():
     vcycles = sim.pois.n[n0:]
 
     mlups = ncell_global * args.steps / elapsed / 1e6
-    avg_ms = ms.value / max(1, nl.value)
-    dense, never, skipped = ALG_T[dominant]
     n_uni, n_rows = S.uniform_rows(sim.pois, 0)
     phi = n_uni / max(1, n_rows)                       # share of x-rows whose L / iD loads are skipped
-    cells_per_launch = nc.value / max(1, nl.value)
-    alg_bytes = dense * tsz * cells_per_launch
-    moved_bytes = (dense - never - phi * skipped) * tsz * cells_per_launch
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    moved_rate = moved_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
+    traffic_db = {}
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile):
+    if os.path.exists(tfile) and not args.grid and world == 1:
         try:
-            traffic = json.load(open(tfile)).get(f"{dominant}@{m}^3/{args.dtype}") if not args.grid else None
+            traffic_db = json.load(open(tfile))
         except Exception:
-            traffic = None
-    # the north-star's named kernel: the V-cycle smoother (fused Jacobi!+increment! and prolongate!+increment!), from
-    # the per-class hipEvent pass above (finest-level launches only)
-    smoother = None
-    if per_class.get("smooth", {}).get("launches"):
-        sm = per_class["smooth"]
-        sm_ms = sm["ms"] / sm["launches"]
-        d_, n_, k_ = ALG_T["smooth"]
-        sm_alg = d_ * tsz * ncell
-        sm_mov = (d_ - n_ - phi * k_) * tsz * ncell
-        smoother = {"kernel": "smooth", "avg_launch_ms": sm_ms, "launches": sm["launches"],
-                    "achieved": sm_alg / (sm_ms * 1e-3) / 1e9, "frac": sm_alg / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "moved_GB/s": sm_mov / (sm_ms * 1e-3) / 1e9, "moved_frac": sm_mov / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "unit": "GB/s", "algorithmic_bytes_per_launch": sm_alg}
+            traffic_db = {}
+
+    def kernel_record(nm, launches, cells, total_ms):
+        """bytes / rates of one kernel class from its launch count, summed cells and summed duration"""
+        if not launches or total_ms <= 0:
+            return None
+        dense, need, extra = ALG_T[nm]
+        avg_ms = total_ms / launches
+        cpl = cells / launches
+        need_b = (need + (1.0 - phi) * extra) * tsz * cpl
+        dense_b = dense * tsz * cpl
+        rate = need_b / (avg_ms * 1e-3) / 1e9
+        drate = dense_b / (avg_ms * 1e-3) / 1e9
+        rec = {"bound": "hbm", "kernel": nm, "achieved": rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate / HBM_PEAK_GBS,
+               "traffic": traffic_db.get(f"{nm}@{m}^3/{args.dtype}"), "launches": launches, "avg_launch_ms": avg_ms,
+               "algorithmic_bytes_per_launch": need_b,
+               "dense": {"bytes_per_launch": dense_b, "GB/s": drate, "frac_of_peak": drate / HBM_PEAK_GBS,
+                         "note": "SURVEY 8(d) per-cell figure of the reference operator; the fused kernel does not move these bytes"}}
+        if rec["traffic"]:
+            rec["traffic_GB/s"] = rec["traffic"] / (avg_ms * 1e-3) / 1e9
+        return rec
+
+    roof = kernel_record(dominant, nl.value, nc.value, ms.value)
+    roof["uniform_row_fraction"] = phi
+    roof["per_class_ms_one_step"] = {k: {"launches": v["launches"], "ms": v["ms"]} for k, v in per_class.items()}
+    sm = per_class.get("smooth")
+    pr = per_class.get("prolongate")
     out = {
         "metric": "MLUPS (cell-updates/s) per sim_step!, 3D sphere", "value": mlups, "unit": "MLUPS",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -267,20 +292,15 @@ def main():
         "config": {"workload": f"3D {args.body} {dims[0]}x{dims[1]}x{dims[2]}, Re={3700 if args.body == 'sphere' else 1000}, {args.dtype}, uniform inflow, "
                                f"remeasure=false" + (", dense layout" if args.layout == "dense" else "") + (" (BASELINE configs[2])" if world == 1 and not args.grid and m == 512
                                                      and args.dtype == "f32" and args.body == "sphere" else "" if world == 1 else
-                                                     f", z-slabs over {world} GPUs ({transport})"),
+                                                     f", z-slabs over {world} GPUs"),
+                   "transport": transport, "comm_ranks": cn.value,
                    "vcycles_per_solve": vcycles[:6], "mean_vcycles_per_step": float(np.sum(vcycles)) / args.steps},
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": nl.value,
-                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "moved": {"bytes_per_launch": moved_bytes, "GB/s": moved_rate, "frac": moved_rate / HBM_PEAK_GBS,
-                               "uniform_row_fraction": phi,
-                               "note": "achieved/frac use the dense algorithmic bytes of SURVEY 8(d); the kernel skips the "
-                                       "loads of L/iD in coefficient-uniform rows and recomputes D, so it moves only "
-                                       "`moved.bytes_per_launch` (compare `traffic`, the PMC-measured bytes)"},
-                     "smoother": smoother, "per_class_ms_one_step": per_class},
+        "roofline": roof,
+        "smoother": kernel_record("smooth", sm["launches"], sm["cells"], sm["ms"]) if sm else None,
+        "prolong_increment": kernel_record("prolongate", pr["launches"], pr["cells"], pr["ms"]) if pr else None,
     }
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps, args.cpu_c1_steps)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

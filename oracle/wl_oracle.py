@@ -521,9 +521,9 @@ def pressure_moment_band(x0, p: np.ndarray, df: np.ndarray, idx: np.ndarray, nds
 # --------------------------------------------------------------------------- WaterLily.jl
 
 class Simulation:
-    """src/WaterLily.jl:59-79.  `body` is any object; `measure_fn(body, N, D, t, eps, T)` must return
-    (mu0, mu1, V, d) host arrays before boundary conditions (Body.jl:32-50) -- tests pass
-    waterlily_amd.body.measure_fields, which is pinned separately by the reference's AutoBody tests."""
+    """src/WaterLily.jl:59-79.  `body`: an oracle.geometry.Body (closed-form sdf/map: measured by oracle.geometry, the
+    default) or any object together with `measure_fn(body, dims, t=, eps=, T=)` returning the (mu0, mu1, V, d) host
+    arrays of Body.jl:32-50 before boundary conditions and `nds_fn(body, dims, t=)` (Metrics.jl:84-87)."""
 
     def __init__(self, dims, u_BC, L, *, dt=0.25, nu=0.0, g=None, U=None, eps=1, perdir=(), ulam=None,
                  exitBC=False, body=None, T=np.float32, measure_fn=None, nds_fn=None):
@@ -534,6 +534,10 @@ class Simulation:
             ulam = (lambda i, x: u_BC(i, 0.0)) if callable(u_BC) else (lambda i, x: u_BC[i])
         self.U = float(np.sqrt(sum(float(v) ** 2 for v in u_BC))) if U is None else U
         self.L, self.eps = L, eps
+        if body is not None and measure_fn is None:
+            from . import geometry as _G
+            assert isinstance(body, _G.Body), "give an oracle.geometry.Body, or measure_fn/nds_fn for any other body"
+            measure_fn, nds_fn = _G.measure_fields, _G.nds_band
         self.body, self._measure_fn, self._nds_fn = body, measure_fn, nds_fn
         self.flow = Flow(dims, u_BC, ulam=ulam, dt=dt, nu=nu, g=g, T=T, perdir=perdir, exitBC=exitBC)
         if body is not None:

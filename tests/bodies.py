@@ -1,0 +1,62 @@
+"""Paired bodies for the parity tests: the SAME geometry once as the product sees it (waterlily_amd.body.AutoBody: user
+closures in torch, differentiated by autograd -- or a parametric body the HIP `measure!` kernel understands) and once as
+the oracle sees it (oracle.geometry.Body: closed-form sdf / map derivatives in numpy).  A parity test hands `.product`
+to waterlily_amd and `.oracle` to oracle.wl_oracle, so no coefficient field the oracle uses was computed by product code.
+The reference bodies these restate: README.md:41-44,118-120 (circle / sphere), SURVEY.md 8d C5 (torus),
+test/maintests.jl:371-384 (move, accel, plate + rotate / bend)."""
+from collections import namedtuple
+
+import torch
+
+from oracle import geometry as G
+from waterlily_amd.body import AutoBody, norm2
+
+Twin = namedtuple("Twin", "product oracle")
+
+
+def _shift(f):
+    """map(x,t) = x - (f(t), 0[, 0])"""
+    def m(x, t):
+        return x - torch.stack([f(t)] + [torch.zeros_like(t)] * (x.shape[0] - 1))[:, None]
+    return m
+
+
+def sphere(center, radius):
+    """circle (2-D) / sphere (3-D): sqrt(sum(abs2, x .- center)) - radius"""
+    return Twin(AutoBody(lambda x, t: norm2(x - center) - radius), G.Body(G.Sphere(center, radius)))
+
+
+def torus(c, R, r):
+    def sdf(x, t):
+        q = torch.sqrt((x[1] - c) ** 2 + (x[2] - c) ** 2) - R
+        return torch.sqrt((x[0] - c) ** 2 + q ** 2) - r
+    return Twin(AutoBody(sdf), G.Body(G.Torus(c, R, r)))
+
+
+def moving_circle(center, radius, v=0.0, a=0.0):
+    """circle translating along x: map(x,t) = x - (v t + a t^2, 0)   (maintests.jl:373-374: move v=1; accel a=2)"""
+    return Twin(AutoBody(lambda x, t: norm2(x - center) - radius, _shift(lambda t: v * t + a * t ** 2)),
+                G.Body(G.Sphere(center, radius), G.Translate(v=(v, 0.0), a=(a, 0.0))))
+
+
+def _plate(radius):
+    return lambda x, t: norm2(x - torch.stack([torch.clamp(x[0], -radius + 2, radius - 2), torch.zeros_like(x[0])])) - 2
+
+
+def rotating_plate(radius):
+    """maintests.jl:375-379"""
+    def rotate(x, t):
+        s, c = torch.sin(t / radius + 1), torch.cos(t / radius + 1)
+        e = x - 2 * radius
+        return torch.stack([c * e[0] + s * e[1], -s * e[0] + c * e[1]])
+    return Twin(AutoBody(_plate(radius), rotate), G.Body(G.Plate(radius - 2, 2.0), G.Rotate2D(2 * radius, 1 / radius, 1.0)))
+
+
+def bending_plate(radius):
+    """maintests.jl:375,380-383"""
+    def bend(xy, t):
+        x, y = xy[0] - 2 * radius, xy[1] - 2 * radius
+        k = 2 * t / radius ** 2 + 0.2 / radius
+        return torch.stack([x + x ** 3 * k ** 2 / 6, y - x ** 2 * k / 2])
+    return Twin(AutoBody(_plate(radius), bend),
+                G.Body(G.Plate(radius - 2, 2.0), G.Bend2D(2 * radius, 2 / radius ** 2, 0.2 / radius)))

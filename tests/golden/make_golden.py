@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz from the CPU oracle (run AFTER tests/test_oracle_pins.py is green).
 
-The reference (Julia) cannot run in this environment and ships no golden data, so these vectors are outputs of
-the pinned oracle on small seeded inputs.  They freeze the oracle's behaviour (a regression guard for the checker
-itself) and give the GPU box a second, oracle-independent target.  Inputs are stored next to the outputs.
+The reference (Julia) cannot run in this environment and ships no golden data, so these vectors are OUTPUTS OF THE
+PINNED ORACLE (oracle/wl_oracle.c for the flow and the pressure solver, oracle/geometry.py for the body) on small seeded
+inputs -- they are oracle-generated, not reference-generated.  They freeze the oracle's behaviour (a regression guard
+for the checker itself) and let the GPU box check the HIP path against committed data.  Inputs are stored next to the
+outputs.  No product code (waterlily_amd) takes part in generating them.
 
     python tests/golden/make_golden.py
 """
@@ -14,9 +16,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import geometry as G  # noqa: E402
 from oracle import wl_oracle as O  # noqa: E402
-from waterlily_amd import body as B  # noqa: E402
-from waterlily_amd.body import AutoBody, norm2  # noqa: E402
 
 
 def rnd(shape, T, seed, lo=-1.0, hi=1.0):
@@ -47,9 +48,8 @@ def poisson_case(Ng, T, seed):
 def sim_case(dims, T, nsteps, Re):
     m = dims[-1]
     R, c = m / 8, m / 2 - 1
-    body = AutoBody(lambda x, t: norm2(x - c) - R)
     U = (1.0,) + (0.0,) * (len(dims) - 1)
-    s = O.Simulation(dims, U, 2 * R, nu=2 * R / Re, body=body, T=T, measure_fn=B.measure_fields, nds_fn=B.nds_band)
+    s = O.Simulation(dims, U, 2 * R, nu=2 * R / Re, body=G.Body(G.Sphere(c, R)), T=T)
     init = dict(mu0=s.flow.mu0.copy(), mu1=s.flow.mu1.copy(), V=s.flow.V.copy(), u_init=s.flow.u.copy())
     for _ in range(nsteps):
         O.sim_step(s, remeasure=False)

@@ -1,5 +1,6 @@
-"""Size-independent properties checked at a BASELINE size (256^3 Float32 = configs[1]; WL_FULLSIZE=512 runs the same
-checks at the 512^3 headline size), where the CPU oracle is too slow to be the checker:
+"""Size-independent properties checked at the BASELINE sizes -- 256^3 Float32 (configs[1], C2) AND 512^3 Float32
+(configs[2], C3: the headline size), both part of the default `-m gpu` run -- where the CPU oracle is too slow to be
+the checker:
 
   * BC! is idempotent;  conv_diff! of a uniform stream is exactly zero on inside cells;
   * A is symmetric: x.(Ay) == y.(Ax);  mult! is exactly linear under power-of-two scaling;
@@ -17,7 +18,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-N = int(os.environ.get("WL_FULLSIZE", "256"))
+SIZES = [int(v) for v in os.environ.get("WL_FULLSIZE", "256,512").split(",")]
 T = np.float32
 
 
@@ -27,8 +28,16 @@ def S():
     return sim
 
 
+@pytest.fixture(scope="module", params=SIZES, ids=[f"{n}^3" for n in SIZES])
+def N(request):
+    yield request.param
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 @pytest.fixture(scope="module")
-def flow(S):
+def flow(S, N):
     U = (2 / 3, -1 / 3, 0.25)
     a = S.Flow((N, N, N), U, T=T, ulam=lambda i, x: U[i])
     return a, S.MultiLevelPoisson(a.p, a.mu0, a.sigma), U
@@ -86,7 +95,7 @@ def test_restrict_prolongate_identities(S, flow):
     assert abs(sf - sc) <= 1e-6 * max(1.0, float(f.r.double().abs().sum()))
 
 
-def test_projection_divergence_free_and_uniform_stream(S, flow):
+def test_projection_divergence_free_and_uniform_stream(S, flow, N):
     a, ml, U = flow
     S.mom_step(a, ml)
     assert all(1 <= n <= 32 for n in ml.n[-2:])
@@ -99,23 +108,45 @@ def test_projection_divergence_free_and_uniform_stream(S, flow):
         assert float((d.double() ** 2).sum()) < 2e-5 * (N / 16) ** 3
 
 
-def test_hydrostatic_force_on_sphere(S):
-    from waterlily_amd import body as B
-    from waterlily_amd.body import AutoBody, norm2
-    n = min(N, 128)                                            # the band search is host-side: keep it short
-    R, c = n / 4, n / 2
-    body = AutoBody(lambda x, t: norm2(x - c) - R)
-    lay = S.Layout((n + 2,) * 3, T, True)
-    p = lay.alloc((), "cuda:0")
-    yy = torch.arange(n + 2, device="cuda", dtype=torch.float32) - 0.5
-    p.copy_(yy[None, :, None].expand(n + 2, n + 2, n + 2))
-    idx, nds = B.nds_band(body, (n, n, n))
-    force = S.pressure_force_band(p, *S.band_to_device(p, idx, nds))
+def test_hydrostatic_force_on_sphere(S, N):
+    """maintests.jl:341-346 in 3-D at full size, through the whole product path: measure! on the device (band cells),
+    the |d|<=1 band rebuilt from them, wl_pforce.  p = y  =>  force = volume * e_y."""
+    import bodies
+    R, c = N / 4, N / 2
+    sim = S.Simulation((N, N, N), (1.0, 0.0, 0.0), 2 * R, body=bodies.sphere(c, R).product, T=T)
+    yy = torch.arange(N + 2, device="cuda", dtype=torch.float32) - 0.5
+    sim.flow.p.copy_(yy[None, :, None].expand(N + 2, N + 2, N + 2))
+    force = S.pressure_force(sim)
     vol = 4 / 3 * math.pi * R ** 3
     assert np.sum(np.abs(force / vol - np.array([0, 1, 0]))) < 2e-3
 
 
-def test_traffic_saving_switches_do_not_change_a_bit(S):
+def test_rows_per_thread_same_bits(S, flow, N):
+    """wl_set_option(4): the 7-point kernel with one or two rows per thread evaluates the same per-cell expressions:
+    mult!, Jacobi!+increment! and the fused V-cycle smoother give bit-identical fields at full size."""
+    a, ml, U = flow
+    lv = ml.levels[0]
+    inner = (slice(1, -1),) * 3
+    x = lv.layout.alloc((), "cuda:0")
+    x[inner] = rand_like(x[inner], 11)
+    r0 = S.like(x)
+    r0[inner] = rand_like(r0[inner], 12)
+    out = []
+    for rows in (1, 2):
+        S.set_option(4, rows)
+        try:
+            z = S.copy_of(S.mult(ml, x))
+            lv.r.copy_(r0)
+            a.p.zero_()
+            S.Jacobi(ml)                                      # eps = r*iD ; r -= A eps ; x += eps
+            out.append((z, S.copy_of(lv.r), S.copy_of(a.p)))
+        finally:
+            S.set_option(4, 0)
+    for u, v in zip(*out):
+        assert torch.equal(u, v)
+
+
+def test_traffic_saving_switches_do_not_change_a_bit(S, N):
     """The kernels that move fewer bytes than the dense algorithm -- row constants instead of L/iD in coefficient-
     uniform rows (option 9), x += alpha*eps deferred to the direction kernel (8), z' = r*iD recomputed instead of
     stored (13), body-free rows in BDIM! (3) -- evaluate the same expressions: three steps of the sphere case give

@@ -8,15 +8,14 @@ import math
 
 import numpy as np
 import pytest
-import torch
 
+from oracle import geometry as G
 from oracle import wl_oracle as O
-from waterlily_amd import body as B
-from waterlily_amd.body import AutoBody, norm2
 
 
 def sim(*a, **k):
-    return O.Simulation(*a, measure_fn=B.measure_fields, nds_fn=B.nds_band, **k)
+    """bodies are oracle.geometry.Body objects (closed-form sdf/map, numpy): no product code feeds these pins"""
+    return O.Simulation(*a, **k)
 
 
 # ----------------------------------------------------------------------------- util.jl (maintests.jl:5-66)
@@ -238,7 +237,7 @@ def test_circle_in_accelerating_flow():
     radius, H = 32, 16
     c = float(H * radius)
     s = sim((radius * 2 * H, radius * 2 * H), lambda i, t: t if i == 0 else 0.0 * t, radius, U=1,
-            body=AutoBody(lambda x, t: norm2(x - c) - radius))
+            body=G.Body(G.Sphere(c, radius)))
     O.sim_step(s)
     f = O.pressure_force(s) / (math.pi * s.L ** 2)
     assert np.allclose(f, [-1, 0], atol=0.04)
@@ -256,8 +255,8 @@ def test_hydrostatic_pressure_force(T):
     p = O.zeros((N, N), T)
     p[O.inside(p)] = O.loc(-1, (N, N))[1][O.inside(p)].astype(T)
     df = O.zeros((N, N, 2), T)
-    body = AutoBody(lambda x, t: norm2(x - N / 2) - N // 4)
-    idx, nds = B.nds_band(body, (N - 2, N - 2))
+    body = G.Body(G.Sphere(N / 2, N // 4))
+    idx, nds = G.nds_band(body, (N - 2, N - 2))
     force = O.pressure_force_band(p, df, idx, nds)
     assert np.sum(np.abs(force / (math.pi * (N / 4) ** 2) - np.array([0, 1]))) < 2e-3
 
@@ -269,35 +268,12 @@ NU = RADIUS / 250
 NM = (RADIUS * 4, RADIUS * 4)
 
 
-def _circle(x, t):
-    return norm2(x - 2.0 * RADIUS) - RADIUS
-
-
-def _shift(fx):
-    """map x -> x - [fx(t), 0]"""
-    return lambda x, t: x - torch.stack([fx(t), torch.zeros_like(t)])[:, None]
-
-
-def _plate(x, t):
-    cx = torch.clamp(x[0], -RADIUS + 2.0, RADIUS - 2.0)
-    return torch.sqrt((x[0] - cx) ** 2 + x[1] ** 2) - 2
-
-
-def _rotate(x, t):
-    th = t / RADIUS + 1
-    s, c = torch.sin(th), torch.cos(th)
-    y = x - 2.0 * RADIUS
-    return torch.stack([c * y[0] + s * y[1], -s * y[0] + c * y[1]])
-
-
-def _bend(xy, t):
-    x, y = xy[0] - 2.0 * RADIUS, xy[1] - 2.0 * RADIUS
-    k = 2 * t / RADIUS ** 2 + 0.2 / RADIUS
-    return torch.stack([x + x ** 3 * k ** 2 / 6, y - x ** 2 * k / 2])
+_circle = G.Sphere(2.0 * RADIUS, RADIUS)                                       # :372
+_plate = G.Plate(RADIUS - 2.0, 2.0)                                            # :375
 
 
 def test_sim_time_stopping():  # :387-390
-    s = sim(NM, (1, 0), RADIUS, body=AutoBody(_circle), nu=NU, T=np.float32)
+    s = sim(NM, (1, 0), RADIUS, body=G.Body(_circle), nu=NU, T=np.float32)
     assert O.sim_time(s) == 0
     O.sim_step(s, 0.1, remeasure=False)
     assert O.sim_time(s) >= 0.1 > sum(s.flow.dt[:-2]) * s.U / s.L
@@ -307,21 +283,21 @@ def test_sim_time_stopping():  # :387-390
 def test_moving_bodies(exitBC):  # :391-412
     kw = dict(nu=NU, T=np.float32, exitBC=exitBC)
     # remeasure works perfectly when V = U = 1
-    s = sim(NM, (1, 0), RADIUS, body=AutoBody(_circle, _shift(lambda t: t)), **kw)
+    s = sim(NM, (1, 0), RADIUS, body=G.Body(_circle, G.Translate(v=(1.0, 0.0))), **kw)           # move, :373
     O.sim_step(s)
     assert np.allclose(s.flow.u[:, RADIUS - 1, 0], 1, rtol=1e-6 ** 0.5)   # Julia's Float32 `≈`
     # accelerating from U=0 to U=1
-    s = sim(NM, (0, 0), RADIUS, U=1, body=AutoBody(_circle, _shift(lambda t: 2 * t ** 2)), **kw)
+    s = sim(NM, (0, 0), RADIUS, U=1, body=G.Body(_circle, G.Translate(a=(2.0, 0.0))), **kw)      # accel, :374
     O.sim_step(s)
     assert s.pois.n == [2, 1]
     assert s.flow.u.max() > s.flow.V.max() > 0
     # non-uniform V doesn't break
-    s = sim(NM, (0, 0), RADIUS, U=1, body=AutoBody(_plate, _rotate), **kw)
+    s = sim(NM, (0, 0), RADIUS, U=1, body=G.Body(_plate, G.Rotate2D(2.0 * RADIUS, 1 / RADIUS, 1.0)), **kw)   # :376-379
     O.sim_step(s)
     assert s.pois.n == [2, 1]
     assert 1 > s.flow.dt[-1] > 0.5
     # divergent V doesn't break
-    s = sim(NM, (0, 0), RADIUS, U=1, body=AutoBody(_plate, _bend), **kw)
+    s = sim(NM, (0, 0), RADIUS, U=1, body=G.Body(_plate, G.Bend2D(2.0 * RADIUS, 2 / RADIUS ** 2, 0.2 / RADIUS)), **kw)   # :380-383
     O.sim_step(s)
     assert s.pois.n == [2, 1]
     assert 1.2 > s.flow.dt[-1] > 0.8
@@ -333,8 +309,8 @@ def test_viscous_force_and_pressure_moment():
     N = 32
     for D in (2, 3):
         shp = (N,) * D
-        body = AutoBody(lambda x, t: norm2(x - N / 2) - N // 4)
-        idx, nds = B.nds_band(body, tuple(n - 2 for n in shp))
+        body = G.Body(G.Sphere(N / 2, N // 4))
+        idx, nds = G.nds_band(body, tuple(n - 2 for n in shp))
         u = O.zeros(shp + (D,), np.float64)
         df = O.zeros(shp + (D,), np.float64)
         assert np.allclose(O.viscous_force_band(u, 1.0, df, idx, nds), 0)                       # :362-363

@@ -37,16 +37,16 @@ def timed(kclass, fn):
     return ms.value / max(1, nl.value), nl.value
 
 
-def ab(title, kclass, key, fn, algT):
-    res = {0: [], 1: []}
+def ab(title, kclass, key, fn, algT, vals=(1, 0), restore=1):
+    res = {v: [] for v in vals}
     for r in range(reps):
-        for val in (1, 0):
+        for val in vals:
             _lib.check(L.wl_set_option(key, val))
             S.residual(ml)
             t, n = timed(kclass, fn)
             res[val].append(t)
-    _lib.check(L.wl_set_option(key, 1 if key != 4 else 0))
-    for val in (1, 0):
+    _lib.check(L.wl_set_option(key, restore))
+    for val in vals:
         t = float(np.median(res[val]))
         print(f"{title:28s} option[{key}]={val}: {t:7.3f} ms/launch  {algT * 4 * ncell / max(t, 1e-9) / 1e6:7.0f} GB/s alg ({n} launches)")
 
@@ -55,11 +55,14 @@ ab("pcg mult+dot (6T)", "pcg_mult_dot", 0, lambda: S.pcg(ml), 6)
 ab("increment (9T)", "increment", 0, lambda: S.increment(ml), 9)
 ab("residual (8T)", "residual", 0, lambda: S.residual(ml), 8)
 ab("V-cycle smoother (9T)", "smooth", 1, lambda: S.Vcycle(ml), 9)
-print("-- option[4]: 1 = 8 rows / 512 threads per workgroup, 0 = 4 rows / 256 threads")
-ab("pcg mult+dot (6T)", "pcg_mult_dot", 4, lambda: S.pcg(ml), 6)
-ab("increment (9T)", "increment", 4, lambda: S.increment(ml), 9)
-ab("V-cycle smoother (9T)", "smooth", 4, lambda: S.Vcycle(ml), 9)
-_lib.check(L.wl_set_option(4, 0))
+print("-- option[4]: rows per thread of the 7-point kernel (1 | 2)")
+ab("pcg mult+dot (6T)", "pcg_mult_dot", 4, lambda: S.pcg(ml), 6, (1, 2), 0)
+ab("increment (9T)", "increment", 4, lambda: S.increment(ml), 9, (1, 2), 0)
+ab("residual (8T)", "residual", 4, lambda: S.residual(ml), 8, (1, 2), 0)
+ab("V-cycle smoother (9T)", "smooth", 4, lambda: S.Vcycle(ml), 9, (1, 2), 0)
+for nm in ("pcg_update", "pcg_direction", "pcg_init"):
+    t, n = timed(nm, lambda: S.pcg(ml))
+    print(f"{nm:28s} {t:7.3f} ms/launch ({n} launches)")
 
 # BDIM! inside mom_step (option 3 = body-free row flags): needs a body
 import bench  # noqa: E402

@@ -197,8 +197,7 @@ struct wl_mg {
     int permask;
     std::vector<wl_level_desc> lev;
     Scratch sc;
-    std::vector<void *> scr_base, scr;   // one internal level-sized buffer per level (pcg! direction ping-pong)
-    std::vector<void *> rowc;            // per level: row constants of L and iD (k_lrow), 2 values per (j,k) row; D==3 only
+    std::vector<void *> rowc;            // per level: row constants of L and iD (k_lrow), RC_N values per (j,k) row; D==3 only
     int alloc_rowc() {
         const size_t es = t == WL_F32 ? 4 : 8;
         rowc.assign(nlev, nullptr);
@@ -209,27 +208,9 @@ struct wl_mg {
         }
         return 0;
     }
-    int alloc_scratch() {
-        const size_t es = t == WL_F32 ? 4 : 8;
-        scr_base.assign(nlev, nullptr);
-        scr.assign(nlev, nullptr);
-        if (ctx().opt[5] != 1) return 0;   // only the (experimental) fused direction+mult pcg needs the buffers
-        for (int l = 0; l < nlev; ++l) {
-            const wl_grid &g = lev[l].g;
-            if (g.D != 3) continue;
-            const size_t span = (size_t)g.n[2] * (size_t)g.s[2] * es;
-            WL_HIP(hipMalloc(&scr_base[l], span + 512));
-            WL_HIP(hipMemsetAsync(scr_base[l], 0, span + 512, ctx().stream));
-            // same address phase (mod 128 B) as the level's eps array, so that the vector kernels apply
-            const uintptr_t want = reinterpret_cast<uintptr_t>(lev[l].eps) & 127, have = reinterpret_cast<uintptr_t>(scr_base[l]) & 127;
-            scr[l] = static_cast<char *>(scr_base[l]) + ((want - have) & 127);
-        }
-        return 0;
-    }
     void free_scratch() {
-        for (void *p : scr_base) if (p) (void)hipFree(p);
         for (void *p : rowc) if (p) (void)hipFree(p);
-        scr_base.clear(); scr.clear(); rowc.clear();
+        rowc.clear();
     }
 };
 struct wl_flow {
@@ -308,7 +289,7 @@ template <class T, int D> static int mg_vcycle(wl_mg *m, int l, int *pcg_np = nu
     if (!tail) {
         int pre = -1;
         if (l + 2 < m->nlev) WL_TRY((mg_vcycle<T, D>(m, l + 1, pcg_np ? &pre : nullptr)));
-        WL_TRY((op_pcg<T, D>(coarse, 6, m->permask, m->sc.partials, m->sc.st, false, (T *)m->scr[l + 1], pre)));
+        WL_TRY((op_pcg<T, D>(coarse, 6, m->permask, m->sc.partials, m->sc.st, false, pre)));
     }
     if (pcg_np) *pcg_np = -1;
     if (fused) return op_prolong_increment_fused<T, D>(fine, fine.eps, coarse.g, coarse.x, m->sc.partials, pcg_np);
@@ -325,7 +306,7 @@ template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, in
     while (n < itmx) {
         int pre = -1;
         if (m->nlev > 1) WL_TRY((mg_vcycle<T, D>(m, 0, &pre)));
-        WL_TRY((op_pcg<T, D>(p, 6, m->permask, m->sc.partials, m->sc.st, true, (T *)m->scr[0], pre)));
+        WL_TRY((op_pcg<T, D>(p, 6, m->permask, m->sc.partials, m->sc.st, true, pre)));
         WL_TRY((op_L2<T, D>(p, m->sc.partials, m->sc.st, true)));
         WL_TRY(m->sc.fetch());
         ++n;
@@ -816,8 +797,7 @@ int wl_mg_create(wl_mg **out, wl_dtype t, int nlevels, const wl_level_desc *leve
     m->lev.assign(levels, levels + nlevels);
     int rc = m->sc.init();
     if (rc) { delete m; return rc; }
-    rc = m->alloc_scratch();
-    if (!rc) rc = m->alloc_rowc();
+    rc = m->alloc_rowc();
     if (rc) { m->free_scratch(); m->sc.release(); delete m; return rc; }
     rc = wl_mg_update(m);
     if (rc) { m->free_scratch(); m->sc.release(); delete m; return rc; }

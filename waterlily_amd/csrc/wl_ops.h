@@ -397,25 +397,36 @@ int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu
     if constexpr (D == 3) {
         // two passes: (1) 16-B vector kernel streams u (+)= f on the body-free rows, (2) the scalar range kernel below
         // evaluates the general statement on the busy rows only (coalesced per cell; ~5 % of the rows for a sphere)
-        if (rowfree && stencil7_ok<T>(g, u, f)) {
+        if (rowfree && stencil7_ok<T>(g)) {
             using VA = VecA<T>;
-            const int rc = launch_rowvec<T, 0>(WL_K_BDIM, g, [=] __device__(long o, int j, int k, double *, const Pre &) {
-                if (!rowfree[j + gg.n[1] * k]) return;
+            struct Dat { VA f[3], u[3]; int free; };
+            const int rc = launch_rowvec<T, 0, false>(WL_K_BDIM, g,
+                [=] __device__(long o, int j, int k, const Pre &) {
+                    Dat d;
+                    d.free = rowfree[j + gg.n[1] * k];
+                    if (d.free) {
 _Pragma("unroll")
-                for (int c = 0; c < 3; ++c) {
-                    const long q = o + (long)c * gg.sc;
-                    const VA fv = VA::load(f + q);
-                    VA uv;
-                    if (MODE != 1) uv = VA::load(u + q);
-_Pragma("unroll")
-                    for (int v = 0; v < VA::V; ++v) {
-                        const double tmp = (0.5 * 0.0 + 0.0) + (double)fv.v[v];
-                        if (MODE == 1) uv.v[v] = (T)(0.0 + tmp);
-                        else { const T un = (T)((double)uv.v[v] + tmp); uv.v[v] = (MODE == 2) ? (T)((double)un * 0.5) : un; }
+                        for (int c = 0; c < 3; ++c) {
+                            d.f[c] = VA::load(f + o + (long)c * gg.sc);
+                            if (MODE != 1) d.u[c] = VA::load(u + o + (long)c * gg.sc);
+                        }
                     }
-                    uv.store(u + q);
-                }
-            }, nullptr, nullptr);
+                    return d;
+                },
+                [=] __device__(long o, int, int, int, const Dat &d, const auto &, double *, const Pre &) {
+                    if (!d.free) return;
+_Pragma("unroll")
+                    for (int c = 0; c < 3; ++c) {
+                        VA uv = d.u[c];
+_Pragma("unroll")
+                        for (int v = 0; v < VA::V; ++v) {
+                            const double tmp = (0.5 * 0.0 + 0.0) + (double)d.f[c].v[v];
+                            if (MODE == 1) uv.v[v] = (T)(0.0 + tmp);
+                            else { const T un = (T)((double)uv.v[v] + tmp); uv.v[v] = (MODE == 2) ? (T)((double)un * 0.5) : un; }
+                        }
+                        uv.store(u + o + (long)c * gg.sc);
+                    }
+                }, (const T *)nullptr, nullptr, nullptr);
             WL_TRY(halo_end());
             if (rc > 0) return rc;
             if (rc == 0) skip_free = true;
@@ -582,35 +593,55 @@ __global__ __launch_bounds__(64 * S7_BY) void k_correct3(G g, T *__restrict__ u,
     if (i > g.n[0] - 2 || j > g.n[1] - 2 || k0 >= k1) return;
     const long sy = g.s[1], sz = g.s[2], sc = g.sc;
     const long col = (long)i + sy * (long)j;
-    VA xm = VA::load(x + col + sz * (k0 - 1));
     const int ju = __builtin_amdgcn_readfirstlane(j);
-    const T *rcp = rowc ? rowc + RC_N * ((long)ju + (long)g.n[1] * k0) : nullptr;
-    for (int k = k0; k < k1; ++k) {
+    const long n1 = g.n[1];
+    // software pipeline: the operands of plane k+1 are requested before plane k is computed and stored
+    struct Pl { VA xc, xy, u0, u1, u2; T left; };
+    auto request = [&](int k) {
         const long o = col + sz * k;
-        const VA xc = VA::load(x + o), xy = VA::load(x + o - sy);
-        T left = __shfl_up(xc.v[V - 1], 1, 64);
-        if (lane == 0) left = x[o - 1];
-        VA u0 = VA::load(u + o), u1 = VA::load(u + o + sc), u2 = VA::load(u + o + 2 * sc);
-        VA l0, l1, l2;
-        RowC<T> rc;
-        rc.c = rc.lxf = rc.lxl = rc.idc = (T)0;
-        if (rcp) { rc = load_rowc<T>(rcp); rcp += RC_N * (long)g.n[1]; }
-        if (rowc && rc.c == rc.c) {   // the lower faces of the row are all c, except the x-boundary face of cell 1
+        Pl p;
+        p.xc = VA::load(x + o); p.xy = VA::load(x + o - sy);
+        p.left = (T)0;
+        if (lane == 0) p.left = x[o - 1];
+        p.u0 = VA::load(u + o); p.u1 = VA::load(u + o + sc); p.u2 = VA::load(u + o + 2 * sc);
+        return p;
+    };
+    VA xm = VA::load(x + col + sz * (k0 - 1));
+    // two operand sets alternate (loop unrolled by two): a set is never copied while its loads are outstanding
+    auto step = [&](int k, const Pl &cur, const RowK<T> &rc, Pl &nxt, RowK<T> &rcn) {
+        const long o = col + sz * k;
+        const int kn = min(k + 1, k1 - 1);
+        nxt = request(kn);
+        rcn = rowk_load<T>(rowc, ju + n1 * kn);
+        T left = __shfl_up(cur.xc.v[V - 1], 1, 64);
+        if (lane == 0) left = cur.left;
+        auto plane = [&](auto FAST) {   // two copies: in a coefficient-uniform row nothing can load L (see RowKU)
+            constexpr bool F = decltype(FAST)::value;
+            VA l0, l1, l2;
+            if (F) {   // the lower faces of the row are all c, except the x-boundary face of cell 1
+                l0 = VA::splat(rc.c); l1 = l0; l2 = l0;
+                if (i == 1) l0.v[0] = rc.lxf;
+            } else {
+                l0 = VA::load(L + o); l1 = VA::load(L + o + sc); l2 = VA::load(L + o + 2 * sc);
+            }
+            VA u0 = cur.u0, u1 = cur.u1, u2 = cur.u2;
 #pragma unroll
-            for (int v = 0; v < V; ++v) { l0.v[v] = rc.c; l1.v[v] = rc.c; l2.v[v] = rc.c; }
-            if (i == 1) l0.v[0] = rc.lxf;
-        } else {
-            l0 = VA::load(L + o); l1 = VA::load(L + o + sc); l2 = VA::load(L + o + 2 * sc);
-        }
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            const T xl = (v == 0) ? left : xc.v[v == 0 ? 0 : v - 1];
-            u0.v[v] -= l0.v[v] * (xc.v[v] - xl);
-            u1.v[v] -= l1.v[v] * (xc.v[v] - xy.v[v]);
-            u2.v[v] -= l2.v[v] * (xc.v[v] - xm.v[v]);
-        }
-        u0.store(u + o); u1.store(u + o + sc); u2.store(u + o + 2 * sc);
-        xm = xc;
+            for (int v = 0; v < V; ++v) {
+                const T xl = (v == 0) ? left : cur.xc.v[v == 0 ? 0 : v - 1];
+                u0.v[v] -= l0.v[v] * (cur.xc.v[v] - xl);
+                u1.v[v] -= l1.v[v] * (cur.xc.v[v] - cur.xy.v[v]);
+                u2.v[v] -= l2.v[v] * (cur.xc.v[v] - xm.v[v]);
+            }
+            u0.store(u + o); u1.store(u + o + sc); u2.store(u + o + 2 * sc);
+        };
+        if (rc.uni()) plane(std::true_type{}); else plane(std::false_type{});
+        xm = cur.xc;
+    };
+    Pl A = request(k0), B;
+    RowK<T> rA = rowk_load<T>(rowc, ju + n1 * k0), rB = rowk_none<T>();
+    for (int k = k0; k < k1; k += 2) {
+        step(k, A, rA, B, rB);
+        if (k + 1 < k1) step(k + 1, B, rB, A, rA);
     }
 }
 
@@ -618,7 +649,7 @@ __global__ __launch_bounds__(64 * S7_BY) void k_correct3(G g, T *__restrict__ u,
 template <class T, int D>
 int op_correct(const G &g, T *u, const T *L, const T *x, const T *rowc = nullptr) {
     if constexpr (D == 3) {
-        if (stencil7_ok<T>(g, u, L) && stencil7_ok<T>(g, x, L)) {
+        if (stencil7_ok<T>(g)) {
             constexpr int V = Vec16<T>::V;
             const Range R = r_inside(g);
             if (R.count() <= 0) return 0;
@@ -729,12 +760,12 @@ int op_residual(const LevelT<T> &p, int permask, double *partials, State *st) {
     int rcv = -1;
     bool exchanged = false;
     if constexpr (D == 3) {
-        if (stencil7_ok<T>(p.g, p.x, p.L) && stencil7_ok<T>(p.g, p.r, p.iD) && stencil7_ok<T>(p.g, p.z, p.L)) {
+        if (stencil7_ok<T>(p.g)) {
             using VA = VecA<T>;
             exchanged = true;
             rcv = launch_stencil7_halo<T, 1>(WL_K_RESIDUAL, p.g, p.x, SrcArray<T>{p.x}, p.L, p.rowc, (const T *)nullptr, p.z,
-                [=] __device__(long o, int j, int k, const VA &ax, const VA &, const VA &, const VA &zz, double *acc, const Pre &) {
-                const VA id = load_iD<T>(q.iD, q.rowc, q.g.n[0], q.g.n[1], o, (int)(o - q.g.s[1] * j - q.g.s[2] * k), j, k);
+                [=] __device__(long o, int i, int, int, const VA &ax, const VA &, const VA &, const VA &zz, const auto &rk, double *acc, const Pre &) {
+                const VA id = row_iD<T>(rk, q.iD, o, i, q.g.n[0]);
                 VA rv;
 _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) {
@@ -775,11 +806,11 @@ int op_increment(const LevelT<T> &p, int permask) {
     const LevelT<T> q = p;
     bool exchanged = false;
     if constexpr (D == 3) {
-        if (stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.r, p.x)) {
+        if (stencil7_ok<T>(p.g)) {
             using VA = VecA<T>;
             exchanged = true;
             const int rcv = launch_stencil7_halo<T, 0>(WL_K_INCREMENT, p.g, p.eps, SrcArray<T>{p.eps}, p.L, p.rowc, p.r, p.x,
-                [=] __device__(long o, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
+                [=] __device__(long o, int, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, const auto &, double *, const Pre &) {
                 VA rv = r0, xv = x0;
 _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
@@ -822,11 +853,11 @@ int op_smooth_fused(const LevelT<T> &p, T *rout) {
     const LevelT<T> q = p;
     bool exchanged = false;
     if constexpr (D == 3) {
-        if (stencil7_ok<T>(p.g, p.r, p.L) && stencil7_ok<T>(p.g, p.iD, p.x) && stencil7_ok<T>(p.g, rout, p.L)) {
+        if (stencil7_ok<T>(p.g)) {
             using VA = VecA<T>;
             exchanged = true;
-            const int rcv = launch_stencil7_halo<T, 0>(WL_K_SMOOTH, p.g, p.r, SrcJacobi<T>{p.r, p.iD, p.rowc, p.g.n[0], p.g.n[1]}, p.L, p.rowc,
-                p.r, p.x, [=] __device__(long o, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
+            const int rcv = launch_stencil7_halo<T, 0>(WL_K_SMOOTH, p.g, p.r, SrcJacobi<T>{p.r, p.iD, p.g.n[0]}, p.L, p.rowc,
+                p.r, p.x, [=] __device__(long o, int, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, const auto &, double *, const Pre &) {
                     VA rv = r0, xv = x0;
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
@@ -871,19 +902,19 @@ int op_prolong_increment_fused(const LevelT<T> &p, const T *rin, const G &gc, co
     const G C = gc;
     if (pcg_np) *pcg_np = -1;
     if constexpr (D == 3) {
-        if (stencil7_ok<T>(p.g, p.r, p.L) && stencil7_ok<T>(p.g, rin, p.x)) {
+        if (stencil7_ok<T>(p.g)) {
             using VA = VecA<T>;
             const SrcProlong<T> src{cx, C, p.g.n[0], p.g.n[1], p.g.nzg, p.g.kz0};
-            if (pcg_np && partials && ctx().opt[10] && ctx().opt[13] && ctx().opt[5] == 2 && !ctx().opt[4] && stencil7_ok<T>(p.g, p.eps, p.iD)) {
+            if (pcg_np && partials && ctx().opt[10] && ctx().opt[13] && ctx().opt[5]) {
                 T *e0 = p.eps;
                 const int tpp = (((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 3) / 4) + 7) / 8 * 8;
                 const int keep = ctx().opt[11];
                 if (tpp <= 1024) ctx().opt[11] = 1024 / tpp;   // few partials: pcg!'s first mult kernel may sum them itself
                 int np = 0;
-                const int rcv = launch_stencil7ab<T, 1>(WL_K_SMOOTH, p.g, src, p.L, p.rowc, rin, p.x,
-                    [=] __device__(long o, int j, int k, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *acc, const Pre &) {
+                const int rcv = launch_stencil7<T, 1>(WL_K_PROLONG, p.g, src, p.L, p.rowc, rin, p.x,
+                    [=] __device__(long o, int i, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, const auto &rk, double *acc, const Pre &) {
                         VA rv = r0, xv = x0;
-                        const VA id = load_iD<T>(q.iD, q.rowc, q.g.n[0], q.g.n[1], o, (int)(o - q.g.s[1] * j - q.g.s[2] * k), j, k);
+                        const VA id = row_iD<T>(rk, q.iD, o, i, q.g.n[0]);
 _Pragma("unroll")
                         for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
                         rv.store(q.r + o);
@@ -897,8 +928,8 @@ _Pragma("unroll")
                 if (rcv > 0) return rcv;
                 if (rcv == 0) { *pcg_np = np; return 0; }
             }
-            const int rcv = launch_stencil7ab<T, 0>(WL_K_SMOOTH, p.g, src, p.L, p.rowc, rin, p.x,
-                [=] __device__(long o, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, double *, const Pre &) {
+            const int rcv = launch_stencil7<T, 0>(WL_K_PROLONG, p.g, src, p.L, p.rowc, rin, p.x,
+                [=] __device__(long o, int, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, const auto &, double *, const Pre &) {
                     VA rv = r0, xv = x0;
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) { rv.v[v] = rv.v[v] - ae.v[v]; xv.v[v] = xv.v[v] + ec.v[v]; }
@@ -908,7 +939,7 @@ _Pragma("unroll")
             if (rcv >= 0) return rcv;
         }
     }
-    return launch_range(WL_K_SMOOTH, r_inside(p.g), [=] __device__(int i, int j, int k) {
+    return launch_range(WL_K_PROLONG, r_inside(p.g), [=] __device__(int i, int j, int k) {
         const long I = q.g.at(i, j, k);
         const int gi[3] = {i, j, D > 2 ? q.g.kg(k) : 0};          // global fine index
         const int ng[3] = {q.g.n[0], q.g.n[1], q.g.nzg};
@@ -941,12 +972,10 @@ _Pragma("unroll")
 // update kernel into the direction kernel that follows it (which streams eps anyway): one array pass less per
 // iteration (10T instead of 11T for update+direction).  Same per-cell expression, alpha unchanged in between; the :138
 // exit leaves st->xpend so that the direction kernel still applies the owed x update and nothing else.
-// scratch (optional): a level-sized buffer laid out like p.eps; when given (and the vector kernels apply, no periodic
-// direction, level not decomposed) iterations 2..it use the FUSED direction+mult kernel: eps_new = beta*eps + r*iD is
-// evaluated on the fly at the 7 stencil points and written out of place (eps <-> scratch ping-pong), z = r*iD is never
-// stored: 15T instead of 16T per iteration and one launch fewer; per-cell arithmetic unchanged.
+// (A variant that folded the direction update into the next mult kernel -- eps_new evaluated on the fly at the 7 stencil
+// points, one array pass less on paper -- was measured slower and removed: see DESIGN.md "measured dead ends".)
 template <class T, int D>
-int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st, bool want_r2 = false, T *scratch = nullptr,
+int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st, bool want_r2 = false,
            int pre_np = -1) {   // pre_np >= 0: eps = r*iD and the partials of rho are already there (op_prolong_increment_fused)
     const LevelT<T> q = p;
     const Range R = r_inside(p.g);
@@ -954,16 +983,12 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     int np = 0;
     // streaming pcg kernels in 16-B vector form where the layout allows (wl_set_option(5,0) = scalar range kernels)
     bool vec = false;
-    if constexpr (D == 3)
-        vec = ctx().opt[5] != 0 && stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.z, p.r) && stencil7_ok<T>(p.g, p.x, p.iD);
+    if constexpr (D == 3) vec = ctx().opt[5] != 0 && stencil7_ok<T>(p.g);
     using VA = VecA<T>;
-    const bool fusedir = vec && scratch && permask == 0 && !p.g.dist && ctx().opt[5] == 1 && ctx().opt[0] && stencil7_ok<T>(p.g, scratch, p.L) &&
-                         (long)((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 7) / 4) + 8 <= WL_MAXB;
-    T *ecur = p.eps, *eoth = scratch;   // (fusedir) buffer holding the current / next search direction
     const bool xdef = ctx().opt[8] != 0;
     // z' = r*iD (:136) is not stored (wl_set_option(13), default on): the direction kernel recomputes it from r and iD
     // (iD is a row constant away from the body), one array write + one read less per iteration; z keeps A*eps.
-    const bool zrec = ctx().opt[13] != 0 || fusedir;
+    const bool zrec = ctx().opt[13] != 0;
     // No finalize launches (wl_set_option(15), default on; single rank, default kernel forms): the dot products z.eps and
     // r.z' are finished by the NEXT kernel (every workgroup sums the <= 1024 partials and applies the scalar logic, Gate
     // kind 1..3), the state travels through st->slots; only the last update keeps its finalize (it publishes the state).
@@ -971,7 +996,7 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     // workgroups that keeps the in-kernel sums cheap costs the streaming kernels more than the launches it saves
     // (512^3: +0.8 %; 256^3 and every coarser level: -2.8 %).
     const int tpp_v = D == 3 ? (((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 3) / 4) + 7) / 8 * 8 : 0;
-    const bool infin = vec && xdef && zrec && !fusedir && !ctx().opt[4] && R.count() > 0 && tpp_v > 0 &&
+    const bool infin = vec && xdef && zrec && R.count() > 0 && tpp_v > 0 &&
                        (ctx().opt[15] == 2 || (ctx().opt[15] == 1 && R.count() <= (1L << 25))) &&
                        tpp_v <= 1024 && !(p.g.dist && ctx().comm && ctx().comm->size > 1);
     struct CapGuard {   // the in-kernel sums want few partials: cap the number of z-chunks for the kernels of this call
@@ -981,20 +1006,22 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     } capguard(infin, infin ? (1024 / tpp_v > 0 ? 1024 / tpp_v : 1) : 0);
     double *P0 = partials, *PA = infin ? partials + WL_MAXB : partials, *PB = infin ? partials + 2 * WL_MAXB : partials;
     const int f32 = sizeof(T) == 4;
+    const int n0 = p.g.n[0];
     int np0 = 0, npA = 0, cur = 0;   // cur: the slot holding the current state
     // :125-127
     int rv0 = -1;
     if (pre_np >= 0) { rv0 = 0; np = np0 = pre_np; }
     else if (vec) {
-        rv0 = launch_rowvec<T, 1>(WL_K_PCG_INIT, p.g, [=] __device__(long o, int j, int k, double *acc, const Pre &pre) {
-            const VA rr = VA::load(q.r + o);
-            const VA id = load_iD<T>(q.iD, q.rowc, q.g.n[0], q.g.n[1], o, (int)(o - q.g.s[1] * j - q.g.s[2] * k), j, k);
-            VA zv;
+        rv0 = launch_rowvec<T, 1, true>(WL_K_PCG_INIT, p.g,
+            [=] __device__(long o, int, int, const Pre &) { return VA::load(q.r + o); },
+            [=] __device__(long o, int i, int, int, const VA &rr, const auto &rk, double *acc, const Pre &) {
+                const VA id = row_iD<T>(rk, q.iD, o, i, n0);
+                VA zv;
 _Pragma("unroll")
-            for (int v = 0; v < VA::V; ++v) { zv.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zv.v[v]; }
-            if (!zrec) zv.store(q.z + o);
-            zv.store(q.eps + o);
-        }, P0, &np);
+                for (int v = 0; v < VA::V; ++v) { zv.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zv.v[v]; }
+                if (!zrec) zv.store(q.z + o);
+                zv.store(q.eps + o);
+            }, p.rowc, P0, &np);
         if (rv0 > 0) return rv0;
         np0 = np;
     }
@@ -1022,46 +1049,19 @@ _Pragma("unroll")
         // :130-131
         int rcv = -1;
         if constexpr (D == 3) {
-            if (stencil7_ok<T>(p.g, p.eps, p.L) && stencil7_ok<T>(p.g, p.z, p.L)) {
-                using VA = VecA<T>;
-                if (fusedir && n > 1) {   // (never on a decomposed level: no exchange needed)
-                    // [:133 x += alpha*eps of the previous iteration (deferred)] + :140 of the previous iteration +
-                    // :130-131: eps_new = beta*eps + r*iD (out of place: neighbours still read the old eps), z = A eps_new
-                    T *eo = eoth;
-                    const T *eold = ecur;
-                    rcv = launch_stencil7<T, 1>(WL_K_PCG_MULT, p.g,
-                        SrcDirection<T>{ecur, p.r, p.iD, p.rowc, p.g.n[0], p.g.n[1], (T)0}, p.L, p.rowc,
-                        [=] __device__(long o, int, int, const VA &ae, const VA &ec, double *acc, const Pre &pre) {
-                            if (xdef) {
-                                const T alpha = (T)pre.s0;
-                                const VA ev = VA::load(eold + o);
-                                VA xv = VA::load(q.x + o);
-_Pragma("unroll")
-                                for (int v = 0; v < VA::V; ++v) xv.v[v] += alpha * ev.v[v];
-                                xv.store(q.x + o);
-                                if (!pre.act) return;   // only the x update of the :138 exit was owed
-                            }
-                            ec.store(eo + o);
-                            ae.store(q.z + o);
-_Pragma("unroll")
-                            for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];
-                        }, partials, &np, Gate{&st->active, xdef ? &st->xpend : nullptr, &st->alpha, &st->beta});
-                    if (rcv == 0) { T *tmp = ecur; ecur = eoth; eoth = tmp; }
-                } else {
-                const T *esrc = ecur;
+            if (stencil7_ok<T>(p.g)) {
                 exchanged = true;
                 Gate gate_mult;
                 if (!infin) gate_mult.active = &st->active;
                 else if (n == 1) { gate_mult.kind = 1; gate_mult.part = P0; gate_mult.np = np0; gate_mult.out = &st->slots[0]; cur = 0; }
                 else { gate_mult.kind = 4; gate_mult.in = &st->slots[cur]; }
                 gate_mult.eps10 = (double)eps10; gate_mult.f32 = f32;
-                rcv = launch_stencil7_halo<T, 1>(WL_K_PCG_MULT, p.g, ecur, SrcArray<T>{esrc}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
-                    [=] __device__(long o, int, int, const VA &ae, const VA &ec, const VA &, const VA &, double *acc, const Pre &) {
+                rcv = launch_stencil7_halo<T, 1>(WL_K_PCG_MULT, p.g, p.eps, SrcArray<T>{p.eps}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
+                    [=] __device__(long o, int, int, int, const VA &ae, const VA &ec, const VA &, const VA &, const auto &, double *acc, const Pre &) {
                     ae.store(q.z + o);
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];
                 }, PA, &np, gate_mult);
-                }
                 if (rcv > 0) return rcv;
                 if (infin && rcv != 0) return fail(WL_E_STATE, "pcg: vector mult kernel rejected", __FILE__, __LINE__);
                 npA = np;
@@ -1094,32 +1094,38 @@ _Pragma("unroll")
         else { gate_upd.kind = 2; gate_upd.part = PA; gate_upd.np = npA; gate_upd.in = &st->slots[cur]; gate_upd.out = &st->slots[cur ^ 1]; }
         gate_upd.eps10 = (double)eps10; gate_upd.f32 = f32;
         if (vec) {
-            rvu = launch_rowvec<T, 1>(WL_K_PCG_UPDATE, p.g, [=] __device__(long o, int j, int k, double *acc, const Pre &pre) {
-                const T alpha = (T)pre.s0;
-                VA rr = VA::load(q.r + o);
-                const VA zv = VA::load(q.z + o);
-                VA id;   // every load of this plane is issued before its first store
-                if (!last) id = load_iD<T>(q.iD, q.rowc, q.g.n[0], q.g.n[1], o, (int)(o - q.g.s[1] * j - q.g.s[2] * k), j, k);
-                if (xnow) {
-                    VA xv = VA::load(q.x + o);
-                    const VA ev = VA::load(ecur + o);
+            struct UD { VA r, z, x, e; };
+            rvu = launch_rowvec<T, 1, true>(WL_K_PCG_UPDATE, p.g,
+                [=] __device__(long o, int, int, const Pre &) {
+                    UD d;
+                    d.r = VA::load(q.r + o);
+                    d.z = VA::load(q.z + o);
+                    if (xnow) { d.x = VA::load(q.x + o); d.e = VA::load(q.eps + o); }
+                    return d;
+                },
+                [=] __device__(long o, int i, int, int, const UD &d, const auto &rk, double *acc, const Pre &pre) {
+                    const T alpha = (T)pre.s0;
+                    VA rr = d.r;
+                    if (xnow) {
+                        VA xv = d.x;
 _Pragma("unroll")
-                    for (int v = 0; v < VA::V; ++v) xv.v[v] += alpha * ev.v[v];
-                    xv.store(q.x + o);
-                }
+                        for (int v = 0; v < VA::V; ++v) xv.v[v] += alpha * d.e.v[v];
+                        xv.store(q.x + o);
+                    }
 _Pragma("unroll")
-                for (int v = 0; v < VA::V; ++v) rr.v[v] = rr.v[v] - alpha * zv.v[v];
-                rr.store(q.r + o);
-                if (!last) {
-                    VA zn;
+                    for (int v = 0; v < VA::V; ++v) rr.v[v] = rr.v[v] - alpha * d.z.v[v];
+                    rr.store(q.r + o);
+                    if (!last) {
+                        const VA id = row_iD<T>(rk, q.iD, o, i, n0);
+                        VA zn;
 _Pragma("unroll")
-                    for (int v = 0; v < VA::V; ++v) { zn.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zn.v[v]; }
-                    if (!zrec) zn.store(q.z + o);   // (else) the direction kernel recomputes r*iD: z' is never stored
-                } else if (want_r2) {
+                        for (int v = 0; v < VA::V; ++v) { zn.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zn.v[v]; }
+                        if (!zrec) zn.store(q.z + o);   // (else) the direction kernel recomputes r*iD: z' is never stored
+                    } else if (want_r2) {
 _Pragma("unroll")
-                    for (int v = 0; v < VA::V; ++v) acc[0] += (double)rr.v[v] * (double)rr.v[v];
-                }
-            }, PB, &np, gate_upd);
+                        for (int v = 0; v < VA::V; ++v) acc[0] += (double)rr.v[v] * (double)rr.v[v];
+                    }
+                }, p.rowc, PB, &np, gate_upd);
             if (rvu > 0) return rvu;
             if (infin && rvu != 0) return fail(WL_E_STATE, "pcg: vector update kernel rejected", __FILE__, __LINE__);
             if (infin) cur ^= 1;
@@ -1172,38 +1178,45 @@ _Pragma("unroll")
         })));
         if (last) break;
         // :140
-        if (fusedir) continue;   // folded into the next iteration's mult kernel
         int rvd = -1;
         Gate gate_dir;
         if (!infin) { gate_dir.active = &st->active; gate_dir.also = xdef ? &st->xpend : nullptr; gate_dir.s0 = &st->alpha; gate_dir.s1 = &st->beta; }
         else { gate_dir.kind = 3; gate_dir.part = PB; gate_dir.np = np; gate_dir.in = &st->slots[cur]; gate_dir.out = &st->slots[cur ^ 1]; gate_dir.also_x = 1; }
         gate_dir.eps10 = (double)eps10; gate_dir.f32 = f32;
         if (vec) {
-            rvd = launch_rowvec<T, 0>(WL_K_PCG_DIR, p.g, [=] __device__(long o, int j, int k, double *, const Pre &pre) {
+            struct DD { VA e, x, z; };
+            rvd = launch_rowvec<T, 0, true>(WL_K_PCG_DIR, p.g,
                 // gate: runs when pcg is active, or (deferred x) when only the x update of the :138 exit is owed
-                VA ev = VA::load(q.eps + o);
-                VA xv, zv;
-                if (xdef) xv = VA::load(q.x + o);
-                if (pre.act) {
-                    if (zrec) {   // z' = r*iD (:136) recomputed
-                        const VA rr = VA::load(q.r + o);
-                        const VA id = load_iD<T>(q.iD, q.rowc, q.g.n[0], q.g.n[1], o, (int)(o - q.g.s[1] * j - q.g.s[2] * k), j, k);
+                [=] __device__(long o, int, int, const Pre &pre) {
+                    DD d;
+                    d.e = VA::load(q.eps + o);
+                    if (xdef) d.x = VA::load(q.x + o);
+                    if (pre.act) d.z = VA::load((zrec ? q.r : q.z) + o);
+                    return d;
+                },
+                [=] __device__(long o, int i, int, int, const DD &d, const auto &rk, double *, const Pre &pre) {
+                    VA ev = d.e, zv = VA::splat((T)0);
+                    if (pre.act) {
+                        zv = d.z;
+                        if (zrec) {   // z' = r*iD (:136) recomputed
+                            const VA id = row_iD<T>(rk, q.iD, o, i, n0);
 _Pragma("unroll")
-                        for (int v = 0; v < VA::V; ++v) zv.v[v] = rr.v[v] * id.v[v];
-                    } else zv = VA::load(q.z + o);
-                }
-                if (xdef) {   // :133, deferred from the update kernel
-                    const T alpha = (T)pre.s0;
+                            for (int v = 0; v < VA::V; ++v) zv.v[v] = d.z.v[v] * id.v[v];
+                        }
+                    }
+                    if (xdef) {   // :133, deferred from the update kernel
+                        const T alpha = (T)pre.s0;
+                        VA xv = d.x;
 _Pragma("unroll")
-                    for (int v = 0; v < VA::V; ++v) xv.v[v] += alpha * ev.v[v];
-                    xv.store(q.x + o);
-                }
-                if (!pre.act) return;
-                const T beta = (T)pre.s1;
+                        for (int v = 0; v < VA::V; ++v) xv.v[v] += alpha * ev.v[v];
+                        xv.store(q.x + o);
+                    }
+                    if (!pre.act) return;
+                    const T beta = (T)pre.s1;
 _Pragma("unroll")
-                for (int v = 0; v < VA::V; ++v) ev.v[v] = beta * ev.v[v] + zv.v[v];
-                ev.store(q.eps + o);
-            }, nullptr, nullptr, gate_dir);
+                    for (int v = 0; v < VA::V; ++v) ev.v[v] = beta * ev.v[v] + zv.v[v];
+                    ev.store(q.eps + o);
+                }, p.rowc, nullptr, nullptr, gate_dir);
             if (rvd > 0) return rvd;
             if (infin && rvd != 0) return fail(WL_E_STATE, "pcg: vector direction kernel rejected", __FILE__, __LINE__);
             if (infin) cur ^= 1;

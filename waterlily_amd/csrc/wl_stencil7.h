@@ -1,23 +1,34 @@
 // wl_stencil7.h -- the 7-point variable-coefficient operator  A e = D e + sum_d L[I,d] e[I-d] + L[I+d,d] e[I+d]
-// (src/Poisson.jl:69-75) for D=3 as a 16-byte-vectorised z-marching kernel.
+// (src/Poisson.jl:69-75) for D=3 as a 16-byte-vectorised, software-pipelined z-marching kernel, and the 16-byte
+// streaming kernel (no neighbours) that shares its row mapping.
 //
 //   * one lane owns V = 16/sizeof(T) consecutive x cells (float4 / double2): every global access is a 16-B vector
 //     -> 1 KiB per wave instruction, the coalescing sweet spot of gfx950 (16-B aligned in the padded layout);
-//   * a wavefront spans 64*V cells of one row; a 256-thread workgroup = 4 rows; the workgroup marches along z
-//     with a 3-deep register window of e (k-1,k,k+1) and a 2-deep window of L_z, so e and L_z are loaded ONCE
-//     per cell; x neighbours come from the adjacent lane (wave shuffle) -- only the two edge lanes of a row
-//     touch memory for them; y neighbours are aligned vector loads of the rows above/below (L1/L2 hits: the
-//     neighbouring wave of the same workgroup streams that row);
+//   * a wavefront spans 64*V cells of R consecutive rows (R = 1 or 2 rows per thread); a 256-thread workgroup =
+//     4 wavefronts = 4R rows; the workgroup marches along z with a 3-deep register window of e per row, so e is loaded
+//     ONCE per cell; x neighbours come from the adjacent lane (wave shuffle), y neighbours between the rows of one
+//     thread are registers; only the two rows bordering a wavefront's strip are loaded again (L1/L2 hits when the
+//     neighbouring wavefront of the workgroup streams them; the workgroup's outermost halo rows are the only bytes
+//     fetched twice from HBM: 2 per 4R rows);
+//   * SOFTWARE PIPELINE: everything iteration k consumes was requested in iteration k-1 (own rows of plane k+1, halo
+//     rows and edge cells of plane k) -- a source is split into raw() (issue the loads) and xf() (turn what arrived into
+//     e, e.g. r*iD for the fused Jacobi smoother), so no instruction waits for a load issued in the same iteration
+//     except the epilogue operands, which are requested first and consumed last;
 //   * the diagonal is recomputed from the six face coefficients (same operations as set_diag!, Poisson.jl:48-54);
 //   * coefficient-uniform rows: away from the body (and from the domain faces) every face coefficient of a row is
 //     the same number c (1 on the finest level, 2^l below: restrictL! sums four unit faces and halves).  wl_mg_update
-//     records c per row (NaN = not uniform, see k_lrow); in such a row the kernel does not load L at all (3 of the 5
-//     array passes of mult) and uses c -- the very values the loads would have returned, so results are unchanged;
-//   * an epilogue functor epi(o, j, k, Ae, e, acc, pre) turns A e into the operator at hand: z=Ae & z.e (pcg!), r-=Ae & x+=e (increment!),
+//     records c per row (NaN = not uniform, see k_lrow) together with the iD values of the row; in such a row the
+//     kernels load neither L (3 of the 5 array passes of mult) nor iD and use the recorded numbers -- the very values
+//     the loads would have returned, so results are unchanged.  The row constants are read through the CONSTANT address
+//     space with wave-uniform addresses => scalar loads (s_load_dwordx8, scalar cache, lgkmcnt): they neither occupy
+//     vector-memory issue slots nor force the vector loads in flight to drain, and are prefetched one plane ahead;
+//   * an epilogue functor turns A e into the operator at hand: z=Ae & z.e (pcg!), r-=Ae & x+=e (increment!),
 //     r = z-Ax (residual!), with per-thread Float64 partials reduced exactly like the range kernels.
 // Per-cell arithmetic and its order are those of mult()/set_diag! => bit-identical to the generic kernels.
 // Requirements (else the caller falls back to the generic range kernel): D==3 and (n0-2) % V == 0.
 #pragma once
+#include <type_traits>
+
 #include "wl_common.h"
 
 namespace wl {
@@ -45,9 +56,15 @@ template <class T> struct VecA {   // array view of a 16-B vector
         __builtin_memcpy(&q, v, 16);
         *reinterpret_cast<typename Vec16<T>::type *>(p) = q;
     }
+    __device__ __forceinline__ static VecA splat(T x) {
+        VecA r;
+#pragma unroll
+        for (int q = 0; q < V; ++q) r.v[q] = x;
+        return r;
+    }
 };
 
-constexpr int S7_BY = 4;   // rows (= wavefronts) per workgroup of the helper kernels (k_correct3)
+constexpr int S7_BY = 4;   // wavefronts per workgroup of the vector kernels
 
 // Device-side gate and scalars of a solver kernel, read ONCE per thread before its z loop (uniform addresses): inside
 // the loop they would be re-loaded every plane (the stores in between may alias them as far as the compiler knows),
@@ -132,191 +149,267 @@ __device__ __forceinline__ bool gate_open(const Gate &gt, Pre &pre) {
     return s.active || (gt.also_x && s.xpend);
 }
 
-// ---- stencil operand sources: vec(o,i,j,k) = the V cells starting at (i,j,k) [offset o], scal = one cell
-// init(pre): called once per thread before the z loop with the gate's scalars (only SrcDirection uses them)
-template <class T> struct SrcArray {          // e is an array (pcg!: eps, residual!: x, increment!: eps)
-    const T *e;
-    __device__ __forceinline__ void init(const Pre &) {}
-    __device__ __forceinline__ VecA<T> vec(long o, int, int, int) const { return VecA<T>::load(e + o); }
-    __device__ __forceinline__ T scal(long o, int, int, int) const { return e[o]; }
-};
-// iD of the V cells at (i..i+V-1, j, k): the row constant where the row is coefficient-uniform (k_lrow; the two end
-// cells of a row are excluded from that guarantee, so the vectors holding them are loaded), else the array.
-// j and k must be wave-uniform (they are: a wavefront works on one row).
-// Row constants (k_lrow): RC_N values per x-row (j,k) of a level: [c, lxf, lxl, idc, idf, idl, -, -]
+// ---- row constants (k_lrow): RC_N values per x-row (j,k) of a level: [c, idc, idf, idl, lxf, lxl, -, -]
 //   c   = the one value of every face coefficient of the row (NaN: the row is not uniform, use the arrays),
-//   lxf, lxl = Lx at the two x-boundary faces (i = 1 and n0-1), idc = iD of the cells 2..n0-3, idf/idl = iD of the end cells.
+//   idc = iD of the cells 2..n0-3, idf/idl = iD of the two end cells, lxf/lxl = Lx at the two x-boundary faces
+//   (i = 1 and n0-1).  A wavefront works on whole rows, so the row index is wave-uniform and the constants are fetched
+//   with scalar loads through the constant address space (written by k_lrow in an earlier kernel, never by a consumer).
 constexpr int RC_N = 8;
-template <class T> struct RowC { T c, lxf, lxl, idc; };
-template <class T> __device__ __forceinline__ RowC<T> load_rowc(const T *p) {
-    RowC<T> r;
-    if constexpr (sizeof(T) == 4) {
-        const VecA<T> a = VecA<T>::load(p);
-        r.c = a.v[0]; r.lxf = a.v[1]; r.lxl = a.v[2]; r.idc = a.v[3];
-    } else {
-        const VecA<T> a = VecA<T>::load(p), b = VecA<T>::load(p + 2);
-        r.c = a.v[0]; r.lxf = a.v[1]; r.lxl = b.v[0]; r.idc = b.v[1];
-    }
+template <class T> struct RowK {
+    T c, idc, idf, idl, lxf, lxl;
+    __device__ __forceinline__ bool uni() const { return c == c; }
+};
+// the same constants of a row KNOWN (at compile time) to be uniform: consumers that branch on uni() lose the branch and
+// the array loads behind it.  The kernels test uniformity ONCE per plane for all rows involved and run one of two
+// copies of the plane body -- in the all-uniform copy no instruction can load L or iD, so the loads in flight (the
+// prefetch of the next plane) are never drained on behalf of a rarely-taken path (the compiler cannot bound the age of
+// a load that MAY have been issued into a register: it waits for vmcnt(0)).
+template <class T> struct RowKU : RowK<T> {
+    __device__ __forceinline__ RowKU(const RowK<T> &r) : RowK<T>(r) {}
+    __device__ __forceinline__ constexpr bool uni() const { return true; }
+};
+template <class T> __device__ __forceinline__ RowK<T> rowk_none() {
+    RowK<T> r;
+    r.c = __builtin_nanf("");
+    r.idc = r.idf = r.idl = r.lxf = r.lxl = (T)0;
     return r;
 }
-template <class T>
-__device__ __forceinline__ VecA<T> load_iD(const T *iD, const T *rowc, int n0, int n1, long o, int i, int j, int k) {
+// row = j + n1*k, wave-uniform (callers pass values that went through readfirstlane); rowc == nullptr -> "not uniform"
+template <class T> __device__ __forceinline__ RowK<T> rowk_load(const T *rowc, long row) {
+    if (!rowc) return rowk_none<T>();
+    typedef T wl_rc8 __attribute__((ext_vector_type(8)));
+    typedef const __attribute__((address_space(4))) wl_rc8 *cptr;
+    const wl_rc8 a = *(cptr)(rowc + RC_N * row);
+    RowK<T> r;
+    r.c = a[0]; r.idc = a[1]; r.idf = a[2]; r.idl = a[3]; r.lxf = a[4]; r.lxl = a[5];
+    return r;
+}
+// iD of the V cells starting at interior cell i of a row with constants rk (uniform row), or from the array
+template <class T, class RKT>
+__device__ __forceinline__ VecA<T> row_iD(const RKT &rk, const T *iD, long o, int i, int n0) {
     constexpr int V = VecA<T>::V;
-    if (rowc) {
-        const T *rc = rowc + RC_N * ((long)__builtin_amdgcn_readfirstlane(j) + (long)n1 * __builtin_amdgcn_readfirstlane(k));
-        const T c = rc[0];
-        if (c == c) {
-            const T idc = rc[3];
-            VecA<T> b;
-#pragma unroll
-            for (int v = 0; v < V; ++v) b.v[v] = idc;
-            if (i == 1) b.v[0] = rc[4];
-            if (i + V - 1 == n0 - 2) b.v[V - 1] = rc[5];
-            return b;
-        }
+    if (rk.uni()) {
+        VecA<T> b = VecA<T>::splat(rk.idc);
+        if (i == 1) b.v[0] = rk.idf;
+        if (i + V - 1 == n0 - 2) b.v[V - 1] = rk.idl;
+        return b;
     }
     return VecA<T>::load(iD + o);
 }
+// iD of the single cell ii (any index 0..n0-1) of such a row; ghost cells carry iD = 0 (set_diag! writes inside only)
+template <class T, class RKT> __device__ __forceinline__ T row_iD1(const RKT &rk, const T *iD, long o, int ii, int n0) {
+    if (rk.uni()) return (ii < 1 || ii > n0 - 2) ? (T)0 : (ii == 1 ? rk.idf : (ii == n0 - 2 ? rk.idl : rk.idc));
+    return iD[o];
+}
 
+// ---- stencil operand sources.  raw(o,i,j,k) issues the loads of the V cells starting at (i,j,k) [offset o];
+// xf(raw, rk, o, i) turns them into e once they have arrived (rk = row constants of that row); sraw / sxf do the same
+// for ONE cell (the x neighbour of a wavefront's first / last lane).  NEED_ID: xf uses the row's iD constants.
+template <class T> struct SrcArray {          // e is an array (pcg!: eps, residual!: x, increment!: eps)
+    static constexpr bool NEED_ID = false;
+    using Raw = VecA<T>;
+    const T *e;
+    __device__ __forceinline__ Raw raw(long o, int, int, int) const { return VecA<T>::load(e + o); }
+    template <class RKT> __device__ __forceinline__ VecA<T> xf(const Raw &a, const RKT &, long, int) const { return a; }
+    __device__ __forceinline__ T sraw(long o, int, int, int) const { return e[o]; }
+    template <class RKT> __device__ __forceinline__ T sxf(T a, const RKT &, long, int) const { return a; }
+};
 template <class T> struct SrcJacobi {         // e = r*iD evaluated on the fly (Jacobi!, src/Poisson.jl:111)
+    static constexpr bool NEED_ID = true;
+    using Raw = VecA<T>;
     const T *r, *iD;
-    const T *rowc;                             // row constants (nullptr: none)
-    int n0, n1;
-    __device__ __forceinline__ void init(const Pre &) {}
-    __device__ __forceinline__ VecA<T> vec(long o, int i, int j, int k) const {
-        const VecA<T> a = VecA<T>::load(r + o), b = load_iD<T>(iD, rowc, n0, n1, o, i, j, k);
+    int n0;
+    __device__ __forceinline__ Raw raw(long o, int, int, int) const { return VecA<T>::load(r + o); }
+    template <class RKT> __device__ __forceinline__ VecA<T> xf(const Raw &a, const RKT &rk, long o, int i) const {
+        const VecA<T> b = row_iD<T>(rk, iD, o, i, n0);
         VecA<T> c;
 #pragma unroll
         for (int v = 0; v < VecA<T>::V; ++v) c.v[v] = a.v[v] * b.v[v];
         return c;
     }
-    __device__ __forceinline__ T scal(long o, int, int, int) const { return r[o] * iD[o]; }
-};
-template <class T> struct SrcDirection {      // e = beta*eps + r*iD : pcg!'s new search direction on the fly (Poisson.jl:136,140)
-    const T *e, *r, *iD;
-    const T *rowc;                             // row constants (nullptr: none)
-    int n0, n1;
-    T b;                                       // beta: taken from the gate's second scalar by init()
-    __device__ __forceinline__ void init(const Pre &pre) { b = (T)pre.s1; }
-    __device__ __forceinline__ VecA<T> vec(long o, int i, int j, int k) const {
-        const VecA<T> ev = VecA<T>::load(e + o), rv = VecA<T>::load(r + o), dv = load_iD<T>(iD, rowc, n0, n1, o, i, j, k);
-        VecA<T> c;
-#pragma unroll
-        for (int v = 0; v < VecA<T>::V; ++v) c.v[v] = b * ev.v[v] + rv.v[v] * dv.v[v];
-        return c;
-    }
-    __device__ __forceinline__ T scal(long o, int, int, int) const { return b * e[o] + r[o] * iD[o]; }
+    __device__ __forceinline__ T sraw(long o, int, int, int) const { return r[o]; }
+    template <class RKT> __device__ __forceinline__ T sxf(T a, const RKT &rk, long o, int ii) const { return a * row_iD1<T>(rk, iD, o, ii, n0); }
 };
 template <class T> struct SrcProlong {        // e[I] = coarse x[down(I)] inside, 0 on ghosts (MultiLevelPoisson.jl:2,34)
+    static constexpr bool NEED_ID = false;
+    using Raw = VecA<T>;
     const T *cx;
     G C;            // coarse grid
     int n0, n1, nzg, kz0;   // fine extents (global along z) and the fine grid's kz0
-    __device__ __forceinline__ void init(const Pre &) {}
-    __device__ __forceinline__ T scal(long, int i, int j, int k) const {
+    __device__ __forceinline__ T sraw(long, int i, int j, int k) const {
         const int kg = k + kz0;
         if (i < 1 || i > n0 - 2 || j < 1 || j > n1 - 2 || kg < 1 || kg > nzg - 2) return (T)0;
         return cx[C.at((i + 1) / 2, (j + 1) / 2, (kg + 1) / 2 - C.kz0)];
     }
-    __device__ __forceinline__ VecA<T> vec(long, int i, int j, int k) const {   // i is odd (1 + V*m), i+V-1 <= n0-2
-        VecA<T> c;
+    __device__ __forceinline__ Raw raw(long, int i, int j, int k) const {   // i is odd (1 + V*m), i+V-1 <= n0-2
         const int kg = k + kz0;
-        if (j < 1 || j > n1 - 2 || kg < 1 || kg > nzg - 2) {
-#pragma unroll
-            for (int v = 0; v < VecA<T>::V; ++v) c.v[v] = 0;
-            return c;
-        }
+        if (j < 1 || j > n1 - 2 || kg < 1 || kg > nzg - 2) return VecA<T>::splat((T)0);
+        VecA<T> c;
         const T *row = cx + C.at(0, (j + 1) / 2, (kg + 1) / 2 - C.kz0);
 #pragma unroll
         for (int v = 0; v < VecA<T>::V; v += 2) { const T p = row[(i + v + 1) / 2]; c.v[v] = p; c.v[v + 1] = p; }
         return c;
     }
+    template <class RKT> __device__ __forceinline__ VecA<T> xf(const Raw &a, const RKT &, long, int) const { return a; }
+    template <class RKT> __device__ __forceinline__ T sxf(T a, const RKT &, long, int) const { return a; }
 };
 
-template <class T, int NRED, int BY, class SRC, class EPI>
-__global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__restrict__ L, const T *__restrict__ rowc, EPI epi,
-                                                  double *partials, int ntx, int tpp, int nblk, int clen, int klo,
-                                                  int khi, Gate gate) {
+// One launch of the 7-point kernel.  R rows per thread.  ea / eb: optional epilogue operand arrays, loaded next to the
+// stencil operands (requested at the top of the iteration, consumed by the epilogue at its end).
+// epi(o, i, j, k, Ae, e, a, b, rk, acc, pre): rk = row constants of the cell's own row in plane k.
+template <class T, int NRED, int R, class SRC, class EPI>
+__global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *__restrict__ L, const T *rowc, const T *ea, const T *eb,
+                                                        EPI epi, double *partials, int ntx, int tpp, int nblk, int clen, int klo,
+                                                        int khi, Gate gate) {
     constexpr int V = Vec16<T>::V;
     using VA = VecA<T>;
+    using Raw = typename SRC::Raw;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x;
     const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);   // XCD-contiguous logical id
     const int ch = lb / tpp, pt = lb - ch * tpp;
-    const int nxi = g.n[0] - 2, nyi = g.n[1] - 2;
+    const int n0 = g.n[0], n1 = g.n[1], nxi = n0 - 2, nyi = n1 - 2;
     const int i = 1 + (pt % ntx) * 64 * V + lane * V;
-    const int j = 1 + (pt / ntx) * BY + wv;
+    const int jb = __builtin_amdgcn_readfirstlane(1 + (pt / ntx) * (S7_BY * R) + wv * R);   // first row of this wavefront's strip
     const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);
     double acc[NRED > 0 ? NRED : 1];
 #pragma unroll
     for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) acc[q] = 0.0;
     Pre pre;
     const bool run = gate_open(gate, pre);
-    src.init(pre);
-    const bool active = run && (i <= nxi) && (j <= nyi) && (k0 < k1);
+    // (n1-2) % R == 0 (launch condition): a strip is either whole or absent
+    const bool active = run && (i <= nxi) && (jb <= nyi) && (k0 < k1);
     if (active) {   // (no barriers below: inactive lanes may simply skip; shuffles only pair active lanes)
         const bool first = (lane == 0), last = (lane == 63) || (i + V > nxi);
         const long sy = g.s[1], sz = g.s[2], sc = g.sc;
-        const long col = (long)i + sy * (long)j;
+        const long col = (long)i + sy * (long)jb;           // row q of the strip: col + q*sy
         const T *Lx = L, *Ly = L + sc, *Lz = L + 2 * sc;
-        // register window of e: planes k-1, k, k+1; plane k+2 is requested in iteration k and consumed in k+1, so that
-        // two planes of e are in flight per wavefront (in a coefficient-uniform row e is the only HBM stream)
-        VA em = src.vec(col + sz * (k0 - 1), i, j, k0 - 1), ec = src.vec(col + sz * k0, i, j, k0);
-        VA ep = src.vec(col + sz * (k0 + 1), i, j, k0 + 1);
-        VA lzc = VA::load(Lz + col + sz * k0);
-        const int ju = __builtin_amdgcn_readfirstlane(j);   // a wavefront works on ONE row: row constants are scalar loads
-        const T *rcp = rowc ? rowc + RC_N * ((long)ju + (long)g.n[1] * k0) : nullptr;
-        const long rcs = RC_N * (long)g.n[1];
-        RowC<T> rn;
-        rn.c = rn.lxf = rn.lxl = rn.idc = (T)0;
-        if (rcp) rn = load_rowc<T>(rcp);
-        for (int k = k0; k < k1; ++k) {
-            const long o = col + sz * k;
-            const RowC<T> rc = rn;
-            const T c = rc.c;
-            const bool uni = rcp && (c == c);
-            if (rcp) { rcp += rcs; rn = load_rowc<T>(rcp); }   // next plane's row constants (plane k1 <= n2-1 exists)
-            const VA ym = src.vec(o - sy, i, j - 1, k), yp = src.vec(o + sy, i, j + 1, k);
-            VA lx, ly0, ly1, lzp;
-            T lxr;
-            if (uni) {   // all faces of this row are c, except possibly the two x-boundary faces (in the row constants)
+        const long rrow = (long)jb;                         // row-constant index of (row q, plane k): rrow + q + n1*k
+        auto RK = [&](int q, int k) { return rowk_load<T>(rowc, rrow + q + (long)n1 * k); };
+        const int kmax = k1;                                // last plane that exists for this chunk (k1 <= n2-1)
+
+        // Everything iteration k consumes that is still IN FLIGHT when the iteration starts: requested by iteration k-1.
+        // Two such sets alternate (the loop is unrolled by two), so a set is never copied while its loads are outstanding
+        // -- a register move of an in-flight load would wait for it at the bottom of the producing iteration.
+        struct Fly {
+            Raw own[R];          // raw own rows of plane k+1
+            RowK<T> rk[R];       // their row constants (plane k+1)
+            Raw hlo, hhi;        // raw halo rows (jb-1, jb+R) of plane k
+            RowK<T> rkl, rkh;    // and their row constants (only when the source needs iD)
+            T lf[R], rg[R];      // raw x-neighbour cells of the strip's first / last lane, plane k
+        };
+        auto request = [&](Fly &f, int k) {   // the set consumed by iteration k
+            const int kn = min(k + 1, kmax);
 #pragma unroll
-                for (int v = 0; v < V; ++v) { lx.v[v] = c; ly0.v[v] = c; ly1.v[v] = c; lzp.v[v] = c; }
-                if (i == 1) lx.v[0] = rc.lxf;
-                lxr = (i + V > nxi) ? rc.lxl : c;
-            } else {
-                lx = VA::load(Lx + o); ly0 = VA::load(Ly + o); ly1 = VA::load(Ly + o + sy); lzp = VA::load(Lz + o + sz);
-                lxr = __shfl_down(lx.v[0], 1, 64);
-                if (last) lxr = Lx[o + V];
+            for (int q = 0; q < R; ++q) {
+                f.own[q] = src.raw(col + q * sy + sz * kn, i, jb + q, kn);
+                f.rk[q] = RK(q, kn);
+                f.lf[q] = (T)0; f.rg[q] = (T)0;
+                if (first) f.lf[q] = src.sraw(col + q * sy + sz * k - 1, i - 1, jb + q, k);
+                if (last) f.rg[q] = src.sraw(col + q * sy + sz * k + V, i + V, jb + q, k);
             }
-            // x neighbours of the vector ends: adjacent lane, or memory at the two ends of the row segment
-            T left = __shfl_up(ec.v[V - 1], 1, 64), right = __shfl_down(ec.v[0], 1, 64);
-            if (first) left = src.scal(o - 1, i - 1, j, k);
-            if (last) right = src.scal(o + V, i + V, j, k);
-            // issued last: nothing in this iteration waits for it (plane k1 is the last one that exists for this chunk)
-            const int kn = (k + 2 <= k1) ? k + 2 : k1;
-            const VA en = src.vec(col + sz * kn, i, j, kn);
-            VA ae;
+            f.hlo = src.raw(col - sy + sz * k, i, jb - 1, k);
+            f.hhi = src.raw(col + R * sy + sz * k, i, jb + R, k);
+            f.rkl = rowk_none<T>(); f.rkh = rowk_none<T>();
+            if (SRC::NEED_ID) { f.rkl = RK(-1, k); f.rkh = RK(R, k); }
+        };
+
+        // ---- prologue: e of planes k0-1, k0 and the first in-flight set
+        VA em[R], ec[R];
+        RowK<T> rk0[R];                                     // own-row constants of plane k
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const T xm = (v == 0) ? left : ec.v[v == 0 ? 0 : v - 1];
-                const T xp = (v == V - 1) ? right : ec.v[v == V - 1 ? v : v + 1];
-                const T lxlo = lx.v[v], lxhi = (v == V - 1) ? lxr : lx.v[v == V - 1 ? v : v + 1];
-                T dg = 0;
-                dg -= (lxlo + lxhi);
-                dg -= (ly0.v[v] + ly1.v[v]);
-                dg -= (lzc.v[v] + lzp.v[v]);
-                T s = ec.v[v] * dg;
-                s += xm * lxlo + xp * lxhi;
-                s += ym.v[v] * ly0.v[v] + yp.v[v] * ly1.v[v];
-                s += em.v[v] * lzc.v[v] + ep.v[v] * lzp.v[v];
-                ae.v[v] = s;
+        for (int q = 0; q < R; ++q) {
+            const long cq = col + q * sy;
+            const Raw a = src.raw(cq + sz * (k0 - 1), i, jb + q, k0 - 1), c = src.raw(cq + sz * k0, i, jb + q, k0);
+            const RowK<T> rkm = RK(q, k0 - 1);
+            rk0[q] = RK(q, k0);
+            em[q] = src.xf(a, rkm, cq + sz * (k0 - 1), i);
+            ec[q] = src.xf(c, rk0[q], cq + sz * k0, i);
+        }
+        Fly A, B;
+        request(A, k0);
+
+        auto step = [&](int k, Fly &cur, Fly &nxt) {
+            const long ok = col + sz * k;
+            const int kn = min(k + 1, kmax);
+            // ---- (1) requests: epilogue operands of this plane first (consumed last), then the set of the NEXT iteration
+            VA av[R], bv[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                if (ea) av[q] = VA::load(ea + ok + q * sy);
+                if (eb) bv[q] = VA::load(eb + ok + q * sy);
             }
-            epi(o, j, k, ae, ec, acc, pre);
-            em = ec; ec = ep; ep = en; lzc = lzp;
+            request(nxt, kn);
+            // ---- (2)+(3) in two copies: every row involved in this plane is coefficient-uniform (no L / iD load can occur),
+            //      or the general form
+            bool fast = true;
+#pragma unroll
+            for (int q = 0; q < R; ++q) fast = fast && rk0[q].uni() && (!SRC::NEED_ID || cur.rk[q].uni());
+            if (SRC::NEED_ID) fast = fast && cur.rkl.uni() && cur.rkh.uni();
+            auto plane = [&](auto FAST) {
+                constexpr bool F = decltype(FAST)::value;
+                using RKT = typename std::conditional<F, RowKU<T>, RowK<T>>::type;
+                // (2) what arrived: e of plane k+1 (own rows), of the halo rows and edge cells of plane k
+                VA ep[R];
+#pragma unroll
+                for (int q = 0; q < R; ++q) ep[q] = src.xf(cur.own[q], RKT(cur.rk[q]), col + q * sy + sz * kn, i);
+                const VA ylo = src.xf(cur.hlo, RKT(cur.rkl), ok - sy, i), yhi = src.xf(cur.hhi, RKT(cur.rkh), ok + R * sy, i);
+                // (3) the stencil, row by row
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    const long o = ok + q * sy;
+                    const RKT rc(rk0[q]);
+                    VA lx, ly0, ly1, lz0, lz1;
+                    T lxr;
+                    if (rc.uni()) {   // all faces of this row are c, except possibly the two x-boundary faces (in the row constants)
+                        lx = VA::splat(rc.c); ly0 = lx; ly1 = lx; lz0 = lx; lz1 = lx;
+                        if (i == 1) lx.v[0] = rc.lxf;
+                        lxr = (i + V > nxi) ? rc.lxl : rc.c;
+                    } else {
+                        lx = VA::load(Lx + o); ly0 = VA::load(Ly + o); ly1 = VA::load(Ly + o + sy);
+                        lz0 = VA::load(Lz + o); lz1 = VA::load(Lz + o + sz);
+                        lxr = __shfl_down(lx.v[0], 1, 64);
+                        if (last) lxr = Lx[o + V];
+                    }
+                    // x neighbours of the vector ends: adjacent lane, or the (prefetched) cell beyond the strip
+                    T left = __shfl_up(ec[q].v[V - 1], 1, 64), right = __shfl_down(ec[q].v[0], 1, 64);
+                    if (first) left = src.sxf(cur.lf[q], rc, o - 1, i - 1);
+                    if (last) right = src.sxf(cur.rg[q], rc, o + V, i + V);
+                    const VA &ym = (q == 0) ? ylo : ec[q == 0 ? 0 : q - 1];
+                    const VA &yp = (q == R - 1) ? yhi : ec[q == R - 1 ? q : q + 1];
+                    VA ae;
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const T xm = (v == 0) ? left : ec[q].v[v == 0 ? 0 : v - 1];
+                        const T xp = (v == V - 1) ? right : ec[q].v[v == V - 1 ? v : v + 1];
+                        const T lxlo = lx.v[v], lxhi = (v == V - 1) ? lxr : lx.v[v == V - 1 ? v : v + 1];
+                        T dg = 0;
+                        dg -= (lxlo + lxhi);
+                        dg -= (ly0.v[v] + ly1.v[v]);
+                        dg -= (lz0.v[v] + lz1.v[v]);
+                        T s = ec[q].v[v] * dg;
+                        s += xm * lxlo + xp * lxhi;
+                        s += ym.v[v] * ly0.v[v] + yp.v[v] * ly1.v[v];
+                        s += em[q].v[v] * lz0.v[v] + ep[q].v[v] * lz1.v[v];
+                        ae.v[v] = s;
+                    }
+                    epi(o, i, jb + q, k, ae, ec[q], ea ? av[q] : ec[q], eb ? bv[q] : ec[q], rc, acc, pre);
+                }
+#pragma unroll
+                for (int q = 0; q < R; ++q) { em[q] = ec[q]; ec[q] = ep[q]; }
+            };
+            if (fast) plane(std::true_type{}); else plane(std::false_type{});
+            // ---- (4) the constants of plane k+1 (arrived: xf used them) become those of the next iteration's own plane
+#pragma unroll
+            for (int q = 0; q < R; ++q) rk0[q] = cur.rk[q];
+        };
+        for (int k = k0; k < k1; k += 2) {
+            step(k, A, B);
+            if (k + 1 < k1) step(k + 1, B, A);
         }
     }
     if (NRED > 0) {
-        block_red<(NRED > 0 ? NRED : 1), BY>(acc, RED_SUM);
+        block_red<(NRED > 0 ? NRED : 1), S7_BY>(acc, RED_SUM);
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int q = 0; q < NRED; ++q) partials[(long)q * gridDim.x + blockIdx.x] = acc[q];
@@ -324,26 +417,46 @@ __global__ __launch_bounds__(64 * BY) void k_stencil7(G g, SRC src, const T *__r
     }
 }
 
-// ---- 16-B vectorised streaming (no neighbours): f(o, j, k, acc) is called once per V-cell vector at element offset o.
-// Same row mapping as k_stencil7 (lane = V cells of a row, wavefront = row segment, workgroup = 4 rows marching in z).
-template <class T, int NRED, class F>
-__global__ __launch_bounds__(256) void k_rowvec(G g, F f, double *partials, int ntx, int tpp, int nblk, int clen, int klo,
-                                                int khi, Gate gate) {
+// ---- 16-B vectorised streaming (no neighbours), software-pipelined: ld(o, j, k, pre) requests the operands of the V
+// cells at element offset o and returns them; st(o, i, j, k, data, rk, acc, pre) consumes them one iteration later (the
+// loads of plane k+1 are in flight while plane k is computed and stored).  RK: hand the row constants to st.
+// Same row mapping as k_stencil7 with R = 1 (lane = V cells of a row, wavefront = row segment, workgroup = 4 rows).
+template <class T, int NRED, bool RK, class LD, class ST>
+__global__ __launch_bounds__(256) void k_rowvec(G g, LD ld, ST st, const T *rowc, double *partials, int ntx, int tpp, int nblk,
+                                                int clen, int klo, int khi, Gate gate) {
     constexpr int V = Vec16<T>::V;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x;
     const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);
     const int ch = lb / tpp, pt = lb - ch * tpp;
-    const int i = 1 + (pt % ntx) * 64 * V + lane * V, j = 1 + (pt / ntx) * 4 + wv;
+    const int i = 1 + (pt % ntx) * 64 * V + lane * V;
+    const int j = __builtin_amdgcn_readfirstlane(1 + (pt / ntx) * 4 + wv);
     const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);
     double acc[NRED > 0 ? NRED : 1];
 #pragma unroll
     for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) acc[q] = 0.0;
     Pre pre;
     const bool run = gate_open(gate, pre);
-    if (run && i <= g.n[0] - 2 && j <= g.n[1] - 2) {
+    if (run && i <= g.n[0] - 2 && j <= g.n[1] - 2 && k0 < k1) {
         const long col = (long)i + g.s[1] * (long)j;
-        for (int k = k0; k < k1; ++k) f(col + g.s[2] * k, j, k, acc, pre);
+        const long n1 = g.n[1];
+        // two operand sets alternate (loop unrolled by two): a set is never copied while its loads are outstanding
+        auto dA = ld(col + g.s[2] * k0, j, k0, pre);
+        using Dat = decltype(dA);
+        Dat dB;
+        RowK<T> rkA = RK ? rowk_load<T>(rowc, j + n1 * k0) : rowk_none<T>(), rkB = rowk_none<T>();
+        auto step = [&](int k, const Dat &cur, const RowK<T> &rkc, Dat &nxt, RowK<T> &rkn) {
+            const int kn = min(k + 1, k1 - 1);
+            nxt = ld(col + g.s[2] * kn, j, kn, pre);
+            rkn = RK ? rowk_load<T>(rowc, j + n1 * kn) : rowk_none<T>();
+            // (two copies of the consumer: in a coefficient-uniform row no instruction can load iD -- see RowKU)
+            if (RK && rkc.uni()) st(col + g.s[2] * k, i, j, k, cur, RowKU<T>(rkc), acc, pre);
+            else st(col + g.s[2] * k, i, j, k, cur, rkc, acc, pre);
+        };
+        for (int k = k0; k < k1; k += 2) {
+            step(k, dA, rkA, dB, rkB);
+            if (k + 1 < k1) step(k + 1, dB, rkB, dA, rkA);
+        }
     }
     if (NRED > 0) {
         block_red<(NRED > 0 ? NRED : 1), 4>(acc, RED_SUM);
@@ -353,26 +466,36 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, F f, double *partials, int 
         }
     }
 }
-template <class T, int NRED, class F>
-inline int launch_rowvec(int kclass, const G &g, F f, double *partials, int *np, Gate gate = Gate()) {
+
+// chunking of the marching axis: `tpp` workgroups per plane, `nown` planes; the grid is tpp*nchunk <= WL_MAXB (also the
+// number of reduction partials); cap > 0 limits the number of chunks (in-kernel partial sums want few partials)
+inline void chunking(int tpp, int nown, int cap, int *clen, int *nchunk) {
+    int want = WL_MAXB / tpp;
+    if (cap > 0 && cap < want) want = cap;
+    if (want < 1) want = 1;
+    if (want > nown) want = nown;
+    *clen = (nown + want - 1) / want;
+    *nchunk = (nown + *clen - 1) / *clen;
+}
+
+template <class T, int NRED, bool RK, class LD, class ST>
+inline int launch_rowvec(int kclass, const G &g, LD ld, ST st, const T *rowc, double *partials, int *np, Gate gate = Gate(),
+                         int kov_lo = 0, int kov_hi = -1) {
     constexpr int V = Vec16<T>::V;
     Range R = r_inside(g);
     if (np) *np = 0;
+    if (kov_hi >= kov_lo) { R.lo[2] = kov_lo > R.lo[2] ? kov_lo : R.lo[2]; R.hi[2] = kov_hi < R.hi[2] ? kov_hi : R.hi[2]; }
     if (R.count() <= 0) return 0;
     const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + 3) / 4;
     const int tpp = ((ntx * nty + 7) / 8) * 8;
-    const int nown = R.hi[2] - R.lo[2] + 1;
-    int want = WL_MAXB / tpp;
-    if (ctx().opt[12] > 0 && ctx().opt[12] < want) want = ctx().opt[12];
-    if (want < 1) want = 1;
-    if (want > nown) want = nown;
-    const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
+    int clen, nchunk;
+    chunking(tpp, R.hi[2] - R.lo[2] + 1, ctx().opt[12], &clen, &nchunk);
     const int nblk = tpp * nchunk;
     if (nblk > WL_MAXB) return -1;
     if (np) *np = nblk;
     Prof p(kclass, R.count());
-    hipLaunchKernelGGL((k_rowvec<T, NRED, F>), dim3(nblk), dim3(256), 0, ctx().stream, g, f, partials, ntx, tpp, nblk, clen,
-                       R.lo[2], R.hi[2], gate);
+    hipLaunchKernelGGL((k_rowvec<T, NRED, RK, LD, ST>), dim3(nblk), dim3(256), 0, ctx().stream, g, ld, st, RK ? rowc : nullptr, partials,
+                       ntx, tpp, nblk, clen, R.lo[2], R.hi[2], gate);
     return (int)hipGetLastError();
 }
 
@@ -407,12 +530,12 @@ __global__ __launch_bounds__(256) void k_lrow(G g, const T *__restrict__ L, cons
     if (lane == 0) {
         T *rc = rowc + RC_N * row;
         rc[0] = bad ? nan : c;
-        rc[3] = idc;
+        rc[1] = idc;
         if (!bad) {
             const long base = g.at(0, j, k);
-            rc[1] = L[base + 1]; rc[2] = L[base + g.n[0] - 1];
-            rc[4] = iD[base + 1]; rc[5] = iD[base + g.n[0] - 2];
-        } else { rc[1] = rc[2] = rc[4] = rc[5] = nan; }
+            rc[2] = iD[base + 1]; rc[3] = iD[base + g.n[0] - 2];
+            rc[4] = L[base + 1]; rc[5] = L[base + g.n[0] - 1];
+        } else { rc[2] = rc[3] = rc[4] = rc[5] = nan; }
         rc[6] = rc[7] = (T)0;
     }
 }
@@ -423,65 +546,47 @@ template <class T> inline int op_lrow(const G &g, const T *L, const T *iD, T *ro
     return (int)hipGetLastError();
 }
 
-// can the vector kernel run on this level?  (e, L: the arrays involved -- kept for call-site symmetry; any element-
-// aligned pointer and any strides will do)
-template <class T> inline bool stencil7_ok(const G &g, const T *e, const T *L) {
+// can the vector kernels run on this level?  (any element-aligned pointers and any strides will do)
+template <class T> inline bool stencil7_ok(const G &g) {
     constexpr int V = Vec16<T>::V;
-    (void)e; (void)L;
     if (!ctx().opt[0]) return false;
     return g.D == 3 && (g.n[0] - 2) % V == 0 && g.n[0] - 2 >= V;
 }
 
-// launch over the owned interior planes; *np = number of partials per reduced value (0 if nothing to do).
-// BY = rows (wavefronts) per workgroup: 4 (256 threads) or 8 (512 threads; fewer y-halo rows re-read at tile edges),
-// selected by wl_set_option(4, .).
-template <class T, int NRED, int BY, class SRC, class EPI>
-inline int launch_stencil7_by(int kclass, const G &g, SRC src, const T *L, const T *rowc, EPI epi, double *partials, int *np, Gate gate,
-                              int kov_lo = 0, int kov_hi = -1) {
+// launch over the owned interior planes (or the plane sub-range [kov_lo,kov_hi]); *np = number of partials per reduced
+// value (0 if nothing to do).  Returns -1 when the level does not fit the launch (caller falls back).
+template <class T, int NRED, int R, class SRC, class EPI>
+inline int launch_stencil7_r(int kclass, const G &g, SRC src, const T *L, const T *rowc, const T *ea, const T *eb, EPI epi,
+                             double *partials, int *np, Gate gate, int kov_lo, int kov_hi) {
     constexpr int V = Vec16<T>::V;
-    Range R = r_inside(g);
+    Range Rg = r_inside(g);
     if (np) *np = 0;
-    if (kov_hi >= kov_lo) { R.lo[2] = kov_lo > R.lo[2] ? kov_lo : R.lo[2]; R.hi[2] = kov_hi < R.hi[2] ? kov_hi : R.hi[2]; }   // plane sub-range
-    if (R.count() <= 0) return 0;
-    const int klo = R.lo[2], khi = R.hi[2];
-    const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + BY - 1) / BY;
+    if (kov_hi >= kov_lo) { Rg.lo[2] = kov_lo > Rg.lo[2] ? kov_lo : Rg.lo[2]; Rg.hi[2] = kov_hi < Rg.hi[2] ? kov_hi : Rg.hi[2]; }
+    if (Rg.count() <= 0) return 0;
+    const int klo = Rg.lo[2], khi = Rg.hi[2];
+    const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + S7_BY * R - 1) / (S7_BY * R);
     const int tpp = ((ntx * nty + 7) / 8) * 8;
-    const int nown = khi - klo + 1;
-    int want = WL_MAXB / tpp;
-    if (ctx().opt[11] > 0 && ctx().opt[11] < want) want = ctx().opt[11];
-    if (want < 1) want = 1;
-    if (want > nown) want = nown;
-    const int clen = (nown + want - 1) / want;
-    const int nchunk = (nown + clen - 1) / clen;
+    int clen, nchunk;
+    chunking(tpp, khi - klo + 1, ctx().opt[11], &clen, &nchunk);
     const int nblk = tpp * nchunk;
     if (nblk > WL_MAXB) return -1;   // plane too large for the partial buffer: caller falls back
     if (np) *np = nblk;
-    Prof p(kclass, R.count());
-    hipLaunchKernelGGL((k_stencil7<T, NRED, BY, SRC, EPI>), dim3(nblk), dim3(64 * BY), 0, ctx().stream, g, src, L, rowc, epi, partials,
-                       ntx, tpp, nblk, clen, klo, khi, gate);
+    Prof p(kclass, Rg.count());
+    hipLaunchKernelGGL((k_stencil7<T, NRED, R, SRC, EPI>), dim3(nblk), dim3(64 * S7_BY), 0, ctx().stream, g, src, L, rowc, ea, eb, epi,
+                       partials, ntx, tpp, nblk, clen, klo, khi, gate);
     return (int)hipGetLastError();
 }
+// rows per thread: wl_set_option(4, .): 1 or 2 forced; 0 (default) = 2 on levels of at least 2^24 interior cells whose
+// y extent is even (half the halo-row traffic; the larger register window costs occupancy, which only the big levels
+// can afford to trade), else 1
 template <class T, int NRED, class SRC, class EPI>
-inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, const T *rowc, EPI epi, double *partials, int *np,
-                           Gate gate = Gate(), int kov_lo = 0, int kov_hi = -1) {
-    if (ctx().opt[4]) return launch_stencil7_by<T, NRED, 8>(kclass, g, src, L, rowc, epi, partials, np, gate, kov_lo, kov_hi);
-    return launch_stencil7_by<T, NRED, 4>(kclass, g, src, L, rowc, epi, partials, np, gate, kov_lo, kov_hi);
-}
-// Launch with two epilogue operand arrays: EPI(o, j, k, Ae, e, a, b, acc, pre) receives the V values of ea and eb at o
-// (e.g. r and x of increment!), loaded next to the stencil operands.  (A software-pipelined variant of the kernel --
-// loads of plane k+1/k+2 issued one iteration ahead, sources split into load/arithmetic halves -- was measured at
-// 512^3 and 256^3: no gain, 124-152 VGPRs; the kernels are not latency-bound.  See DESIGN.md.)
-template <class T, int NRED, class SRC, class EPI>
-inline int launch_stencil7ab(int kclass, const G &g, SRC src, const T *L, const T *rowc, const T *ea, const T *eb, EPI epi,
-                             double *partials, int *np, Gate gate = Gate(), int kov_lo = 0, int kov_hi = -1) {
-    using VA = VecA<T>;
-    return launch_stencil7<T, NRED>(kclass, g, src, L, rowc,
-        [=] __device__(long o, int j, int k, const VA &ae, const VA &ec, double *acc, const Pre &pre) {
-            VA a = ec, b = ec;
-            if (ea) a = VA::load(ea + o);
-            if (eb) b = VA::load(eb + o);
-            epi(o, j, k, ae, ec, a, b, acc, pre);
-        }, partials, np, gate, kov_lo, kov_hi);
+inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, const T *rowc, const T *ea, const T *eb, EPI epi,
+                           double *partials, int *np, Gate gate = Gate(), int kov_lo = 0, int kov_hi = -1) {
+    const int want = ctx().opt[4];
+    const bool even = ((g.n[1] - 2) % 2) == 0;
+    const bool two = even && (want == 2 || (want == 0 && r_inside(g).count() >= (1L << 24)));
+    if (two) return launch_stencil7_r<T, NRED, 2>(kclass, g, src, L, rowc, ea, eb, epi, partials, np, gate, kov_lo, kov_hi);
+    return launch_stencil7_r<T, NRED, 1>(kclass, g, src, L, rowc, ea, eb, epi, partials, np, gate, kov_lo, kov_hi);
 }
 
 // The same launch on a z-slab level whose operand `hal` (one halo plane per side) has to be exchanged first
@@ -497,18 +602,18 @@ inline int launch_stencil7_halo(int kclass, const G &g, T *hal, SRC src, const T
     const int lo = R.lo[2], hi = R.hi[2];
     if (!g.dist || !overlap_on() || hi - lo + 1 < 3) {
         WL_TRY((halo_exchange<T>(g, hal, 1, 1)));
-        return launch_stencil7ab<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials, np, gate);
+        return launch_stencil7<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials, np, gate);
     }
     WL_TRY((halo_begin<T>(g, hal, 1, 1)));
     ctx().n_overlapped += 1;
     int n1 = 0, n2 = 0, n3 = 0;
-    int rc = launch_stencil7ab<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials, &n1, gate, lo + 1, hi - 1);
+    int rc = launch_stencil7<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials, &n1, gate, lo + 1, hi - 1);
     const int rce = halo_end();
     if (rc) return rc;      // (-1: not applicable -- the exchange has been waited for, the caller's fallback may run)
     if (rce) return rce;
-    rc = launch_stencil7ab<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials ? partials + n1 : nullptr, &n2, gate, lo, lo);
+    rc = launch_stencil7<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials ? partials + n1 : nullptr, &n2, gate, lo, lo);
     if (rc) return rc > 0 ? rc : fail(WL_E_STATE, "split 7-point launch: boundary plane rejected", __FILE__, __LINE__);
-    rc = launch_stencil7ab<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials ? partials + n1 + n2 : nullptr, &n3, gate, hi, hi);
+    rc = launch_stencil7<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials ? partials + n1 + n2 : nullptr, &n3, gate, hi, hi);
     if (rc) return rc > 0 ? rc : fail(WL_E_STATE, "split 7-point launch: boundary plane rejected", __FILE__, __LINE__);
     if (np) *np = n1 + n2 + n3;
     return 0;
