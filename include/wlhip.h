@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 3
+#define WL_ABI_VERSION 4
 
 typedef enum wl_dtype { WL_F32 = 0, WL_F64 = 1 } wl_dtype;
 
@@ -184,6 +184,30 @@ int wl_flow_destroy(wl_flow *a);
  * mu0 == 1 on a whole x-row) that let BDIM! skip those 15 coefficient reads where they are known constants; results
  * are identical with or without the flags.  Until the first call every row takes the general path. */
 int wl_flow_update(wl_flow *a);
+/* measure!(flow, body; t, eps)        src/Body.jl:31-53 for a PARAMETRIC body: an sdf family with closed-form gradient
+ * (what ForwardDiff.gradient returns, src/AutoBody.jl:119) composed with an affine map xi = A x + b evaluated by the
+ * host at the measured time together with its time derivative and inverse (AutoBody.jl:128-130: V = -J \ d(map)/dt).
+ * Bodies defined by arbitrary closures stay on the host side of the ABI (waterlily_amd.body: torch).
+ *   family WL_BODY_SPHERE: p = {c0, c1, c2, radius}  sdf = sqrt(sum(abs2, xi - c)) - radius   (circle when D == 2)
+ *   family WL_BODY_TORUS : p = {c0, c1, c2, R, r}    sdf = norm((xi0-c0, norm((xi1-c1, xi2-c2)) - R)) - r   (D == 3)
+ * Matrices are row-major 3x3 (the upper-left 2x2 block when D == 2). */
+enum { WL_BODY_SPHERE = 0, WL_BODY_TORUS = 1 };
+typedef struct wl_body_desc {
+    int32_t family;
+    int32_t identity_map;   /* != 0: xi = x (A, b, dA, db, Ainv are ignored; V = 0) */
+    double p[8];
+    double A[9], b[3], dA[9], db[3], Ainv[9];
+} wl_body_desc;
+/* Part 1: sigma = sdf at every interior cell centre (Body.jl:34) and the number of band cells d^2 < (2+eps)^2 (:35)
+ * this rank will report (synchronises).  Part 2 (same body / eps): mu0, mu1, V (:36-48), then BC!(mu0,0) and
+ * BC!(V,0,exitBC) (:51-52), the z-slab halo exchange, and the body-free row flags of wl_flow_update; cand_dev (device,
+ * nband entries) receives the band cells as LOCAL dense column-major indices i + n0*(j + n1*k), ascending.
+ * Only x-rows that hold a band / inside cell now, or held one at the previous wl_measure_fill, are rewritten. */
+int wl_measure_rows(wl_flow *a, const wl_body_desc *body, double eps, int64_t *nband);
+int wl_measure_fill(wl_flow *a, const wl_body_desc *body, double eps, int64_t *cand_dev);
+/* nds(body, loc(0,I), t) = n * kern(clamp(d,-1,1))  (src/Metrics.jl:84-87, Float64) for n listed cells (indices as
+ * written by wl_measure_fill): nds_dev[b*D + c] */
+int wl_body_nds(const wl_grid *g, const wl_body_desc *body, const int64_t *cand_dev, int64_t n, double *nds_dev);
 /* project!(a,b,w)                     src/Flow.jl:137-145 */
 int wl_project(wl_flow *a, wl_mg *b, double dt, double w, int *n_iter);
 /* mom_step!(a,b)                      src/Flow.jl:153-169.  dt = a.dt[end]; U = BCTuple(a.U,a.dt,N);
@@ -224,13 +248,11 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  * key 1: 1 = fused V-cycle smoothers (default), 0 = the reference's two-pass Jacobi!/increment!/prolongate!
  * key 2: 1 = LDS-tiled marching conv_diff kernel (default), 0 = generic gather kernel
  * key 3: 1 = BDIM! uses the body-free row flags (default), 0 = general path everywhere
- * key 5: 2 = 16-B vectorised streaming pcg kernels (default), 1 = additionally evaluate the direction update (and the
- *        deferred x update) inside the next mult kernel (set before wl_mg_create; bit-identical, measured SLOWER: the
- *        fused kernel runs at the 7-point kernels' lower bandwidth, 1.12 ms vs 0.33 + 0.52 ms at 512^3), 0 = scalar
- *        range kernels
+ * key 5: != 0 = 16-B vectorised streaming pcg kernels (default), 0 = scalar range kernels
  * key 6: 1 = multigrid levels <= 4096 cells run as one single-workgroup launch per V-cycle (default), 0 = per-op launches
  * key 7: 1 = BC! as one closed-form launch (default), 0 = the reference's sequence of plane loops
- * key 4: rows per workgroup of the vectorised 7-point kernel: 0 = 4 rows / 256 threads (default), 1 = 8 rows / 512
+ * key 4: rows per thread of the vectorised 7-point kernel (a 256-thread workgroup covers 4x that many rows): 1, 2, or
+ *        0 (default) = 2 on levels of >= 2^24 interior cells with an even y extent, else 1.  Same values either way.
  * key 8: 1 = pcg! applies x += alpha*eps in the direction kernel instead of the update kernel (default; one array
  *        pass less per iteration, identical values), 0 = in the update kernel as the reference orders it
  * key 9: 1 = the 7-point kernels skip the loads of L in rows whose face coefficients are all one number (rows clear
@@ -241,6 +263,8 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  * key 15: 1 = on levels of at most 2^25 cells pcg!'s dot products are finished by the kernel that follows (no
  *         one-workgroup finalize launches inside a pcg! call; single rank) (default), 2 = on every level, 0 = separate
  *         finalize launch after every dot product
+ * key 14: 1 = inside mom_step! the predictor's closing `x ./= dt` and the corrector's opening `x .*= 0.5dt`
+ *         (Flow.jl:144,139) are one pass over x, each rounding kept (default), 0 = two passes
  * keys 11, 12: > 0 = cap on the number of z-chunks of the 7-point / streaming vector kernels (measurement only) */
 int wl_set_option(int key, int value);
 

@@ -1,4 +1,4 @@
-# WaterLilyHIPNativeExt.jl -- reference-side binding of libwlhip.so (include/wlhip.h, ABI v3).
+# WaterLilyHIPNativeExt.jl -- reference-side binding of libwlhip.so (include/wlhip.h, ABI v4).
 #
 # NOT EXECUTED by this repository's tests: no Julia runtime exists in the build image or on the GPU box.  It is the
 # shim a WaterLily maintainer would add as a package extension (compare ext/WaterLilyAMDGPUExt.jl): a device array type
@@ -16,6 +16,8 @@ import WaterLily: Flow, Poisson, MultiLevelPoisson, AbstractPoisson, AbstractBod
                   solver!, restrict!, prolongate!, restrictL!, Vcycle!, update!, measure!, apply!, pressure_force,
                   viscous_force, pressure_moment, BCTuple, nds, loc, inside, time
 using StaticArrays
+import KernelAbstractions
+import LinearAlgebra
 
 const lib = get(ENV, "WLHIP_LIB", "libwlhip.so")
 
@@ -61,9 +63,63 @@ Base.Array(a::HIPArray{T,N}) where {T,N} = copyto!(Array{T,N}(undef, a.dims), a)
 Base.copy(a::HIPArray) = HIPArray(Array(a))
 Base.fill!(a::HIPArray{T}, v) where T = iszero(v) ?
     (chk(ccall((:wl_memset0, lib), Cint, (Ptr{Cvoid}, Csize_t), a.ptr, sizeof(T) * length(a))); a) : copyto!(a, fill(T(v), size(a)))
-Base.getindex(a::HIPArray, I...) = Array(a)[I...]                               # tests only (GPUArrays.@allowscalar style)
-Base.sum(a::HIPArray) = sum(Array(a))
-Base.maximum(a::HIPArray) = maximum(Array(a))
+# scalar access = one-element transfers: correct, slow -- only what generic serial code (`julia -t 1` @loop bodies,
+# tests in GPUArrays.@allowscalar style) falls back to
+function Base.getindex(a::HIPArray{T}, I::Vararg{Int}) where T
+    r = Ref{T}(); o = LinearIndices(a.dims)[I...] - 1
+    chk(ccall((:wl_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), r, a.ptr + o * sizeof(T), sizeof(T))); r[]
+end
+function Base.setindex!(a::HIPArray{T}, v, I::Vararg{Int}) where T
+    r = Ref{T}(T(v)); o = LinearIndices(a.dims)[I...] - 1
+    chk(ccall((:wl_h2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), a.ptr + o * sizeof(T), r, sizeof(T))); a
+end
+Base.getindex(a::HIPArray, I::CartesianIndex) = a[Tuple(I)...]
+Base.setindex!(a::HIPArray, v, I::CartesianIndex) = (a[Tuple(I)...] = v)
+
+# ---- Base / LinearAlgebra generics the path calls on arrays (SURVEY.md 8b): device reductions where the library has one.
+# wl_dot / wl_sum / wl_max reduce over inside(a); every array the path reduces (Poisson.jl:94,126-146; Flow.jl:174) has
+# zero ghost entries there, see DESIGN.md section 7.1.  Vector fields (trailing component axis) take the host route.
+function reduce_lib(sym, a::HIPArray{T}, b=nothing) where T
+    o = Ref{Cdouble}()
+    if b === nothing
+        chk(ccall((sym, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ref{Cdouble}), dtype(T), grid(a), a.ptr, o))
+    else
+        chk(ccall((sym, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cdouble}), dtype(T), grid(a), a.ptr, b.ptr, o))
+    end
+    T(o[])
+end
+Base.sum(a::HIPArray{T,N}) where {T,N} = N <= 3 ? reduce_lib(:wl_sum, a) : sum(Array(a))
+Base.maximum(a::HIPArray{T,N}) where {T,N} = N <= 3 ? reduce_lib(:wl_max, a) : maximum(Array(a))
+LinearAlgebra.dot(a::HIPArray{T,N}, b::HIPArray{T,N}) where {T,N} = N <= 3 ? reduce_lib(:wl_dot, a, b) : LinearAlgebra.dot(Array(a), Array(b))
+
+# ---- broadcast (`.=`, `.*=`, `./=`, Flow.jl:37,139,144,154 -- inside mom_step! these never run: the override below
+# replaces the whole step): host fallback, D2H -> Base broadcast -> H2D
+struct HIPStyle <: Broadcast.AbstractArrayStyle{Any} end
+HIPStyle(::Val) = HIPStyle()
+Base.BroadcastStyle(::Type{<:HIPArray}) = HIPStyle()
+hostify(x) = x
+hostify(x::HIPArray) = Array(x)
+hostify(bc::Broadcast.Broadcasted) = Broadcast.broadcasted(bc.f, map(hostify, bc.args)...)
+Base.similar(bc::Broadcast.Broadcasted{HIPStyle}, ::Type{T}) where T = HIPArray{T,length(axes(bc))}(map(length, axes(bc)))
+Base.copyto!(d::HIPArray, bc::Broadcast.Broadcasted{HIPStyle}) = copyto!(d, Array{eltype(d)}(Broadcast.materialize(hostify(bc))))
+Base.copyto!(d::HIPArray{T}, bc::Broadcast.Broadcasted{<:Broadcast.AbstractArrayStyle{0}}) where T = fill!(d, bc[])
+
+# ---- generic @loop / @inside on HIPArray arguments (src/util.jl:119-141): with more than one thread the macro launches a
+# KernelAbstractions kernel on `get_backend(first array)`.  This backend stages the call through the host: D2H every
+# HIPArray argument, run the SAME kernel on KernelAbstractions' CPU backend (the reference Array path), H2D the arrays
+# back.  It makes user code such as `@inside p[I] = ke(I,u)` (Metrics.jl:14-77) or `measure_sdf!` (Body.jl:68) work
+# unchanged on device fields; every operator of the hot path has a native override and never comes here.
+struct HostStaged <: KernelAbstractions.Backend end
+KernelAbstractions.get_backend(::HIPArray) = HostStaged()
+KernelAbstractions.synchronize(::HostStaged) = chk(ccall((:wl_sync, lib), Cint, ()))
+function (k::KernelAbstractions.Kernel{HostStaged})(args...; ndrange=nothing, workgroupsize=nothing)
+    host = map(hostify, args)
+    kc = KernelAbstractions.Kernel{KernelAbstractions.CPU,typeof(k).parameters[2],typeof(k).parameters[3],typeof(k.f)}(KernelAbstractions.CPU(), k.f)
+    kc(host...; ndrange, workgroupsize)
+    KernelAbstractions.synchronize(KernelAbstractions.CPU())
+    foreach((d, h) -> d isa HIPArray && copyto!(d, h), args, host)
+    nothing
+end
 
 grid(a::HIPArray, D=ndims(a)) = (n = (size(a)[1:D]..., ntuple(_ -> 1, 3 - D)...);
     WlGrid(D, Int32.(n), (1, n[1], n[1] * n[2]), prod(n), 0, 0, 0, 0, 0))

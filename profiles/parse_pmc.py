@@ -27,7 +27,7 @@ LAMBDA = {  # (operator, kernel kind, lambda ordinal) -> libwlhip kernel class
 
 
 S7 = {"op_pcg": "pcg_mult_dot", "op_increment": "increment", "op_residual": "residual", "op_smooth_fused": "smooth",
-      "op_prolong_increment_fused": "smooth_prolong"}
+      "op_prolong_increment_fused": "prolongate"}
 
 
 ROWVEC = {("op_pcg", "#1"): "pcg_init", ("op_pcg", "#2"): "pcg_update", ("op_pcg", "#3"): "pcg_direction",
@@ -39,6 +39,10 @@ def classify(name):
         return "conv_diff"
     if "k_correct3" in name:
         return "correct"
+    if "k_measure_fill" in name:
+        return "measure_fill"
+    if "k_measure_rows" in name:
+        return "measure_rows"
     if "k_scale_flat" in name:
         return "scale"
     if "k_rowvec" in name:
@@ -56,6 +60,10 @@ def classify(name):
 
 
 def collect(path, counter):
+    """mean counter value per FINEST-LEVEL dispatch of each kernel class.  The multigrid levels shrink by 8x in cells, so
+    a dispatch belongs to the finest level when its value exceeds a quarter of the class maximum; variants of one class on
+    that level (pcg_update: 5 non-final iterations at 3T and the final one at 6T per pcg! call) all pass, i.e. the mean is
+    over the SAME launch mix bench.py times.  Also returns (count, min, max) per class."""
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
@@ -63,25 +71,30 @@ def collect(path, counter):
         k = classify(r["Kernel_Name"])
         if k:
             per[k].append(float(r["Counter_Value"]) * 1024.0)
-    out = {}
+    out, info = {}, {}
     for k, v in per.items():
         top = max(v)
-        fin = [x for x in v if x > 0.6 * top]  # finest-level dispatches only
+        fin = [x for x in v if x > 0.25 * top]
         out[k] = sum(fin) / len(fin)
-    return out
+        info[k] = (len(fin), min(fin), max(fin))
+    return out, info
 
 
 def main():
     fpath, wpath, tag = sys.argv[1:4]
-    rd = {k: 2.0 * v for k, v in collect(fpath, "FETCH_SIZE").items()}
-    wr = collect(wpath, "WRITE_SIZE")
+    rd, ri = collect(fpath, "FETCH_SIZE")
+    rd = {k: 2.0 * v for k, v in rd.items()}
+    wr, wi = collect(wpath, "WRITE_SIZE")
     here = os.path.dirname(os.path.abspath(__file__))
     tfile = os.path.join(here, "traffic.json")
     data = json.load(open(tfile)) if os.path.exists(tfile) else {}
+    print(f"HBM traffic per finest-level launch, {tag} (FETCH_SIZE doubled per MI355X_MICROARCH.md; mean over the launch mix of the run)")
     for k in sorted(set(rd) | set(wr)):
         tot = rd.get(k, 0.0) + wr.get(k, 0.0)
         data[f"{k}@{tag}"] = tot
-        print(f"{k:14s} read(corrected) {rd.get(k, 0) / 1e9:7.3f} GB  write {wr.get(k, 0) / 1e9:7.3f} GB  total {tot / 1e9:7.3f} GB/launch")
+        n, lo, hi = ri.get(k, (0, 0, 0))
+        spread = f"  [{n} launches, reads {2 * lo / 1e9:.2f}..{2 * hi / 1e9:.2f} GB]" if n else ""
+        print(f"{k:14s} read(corrected) {rd.get(k, 0) / 1e9:7.3f} GB  write {wr.get(k, 0) / 1e9:7.3f} GB  total {tot / 1e9:7.3f} GB/launch{spread}")
     json.dump(data, open(tfile, "w"), indent=1, sort_keys=True)
 
 

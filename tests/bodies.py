@@ -9,9 +9,12 @@ from collections import namedtuple
 import torch
 
 from oracle import geometry as G
+from waterlily_amd import body as B
 from waterlily_amd.body import AutoBody, norm2
 
-Twin = namedtuple("Twin", "product oracle")
+# product: closures (torch + autograd); oracle: closed forms (numpy); native: the same body as a waterlily_amd parametric
+# body, measured by the HIP kernels of csrc/wl_measure.h (None where the family / map has no native form)
+Twin = namedtuple("Twin", "product oracle native", defaults=(None,))
 
 
 def _shift(f):
@@ -23,20 +26,34 @@ def _shift(f):
 
 def sphere(center, radius):
     """circle (2-D) / sphere (3-D): sqrt(sum(abs2, x .- center)) - radius"""
-    return Twin(AutoBody(lambda x, t: norm2(x - center) - radius), G.Body(G.Sphere(center, radius)))
+    return Twin(AutoBody(lambda x, t: norm2(x - center) - radius), G.Body(G.Sphere(center, radius)),
+                lambda D: B.Sphere(center, radius, D))
 
 
 def torus(c, R, r):
     def sdf(x, t):
         q = torch.sqrt((x[1] - c) ** 2 + (x[2] - c) ** 2) - R
         return torch.sqrt((x[0] - c) ** 2 + q ** 2) - r
-    return Twin(AutoBody(sdf), G.Body(G.Torus(c, R, r)))
+    return Twin(AutoBody(sdf), G.Body(G.Torus(c, R, r)), lambda D: B.Torus(c, R, r))
 
 
-def moving_circle(center, radius, v=0.0, a=0.0):
-    """circle translating along x: map(x,t) = x - (v t + a t^2, 0)   (maintests.jl:373-374: move v=1; accel a=2)"""
+def moving_circle(center, radius, v=0.0, a=0.0, D=2):
+    """circle / sphere translating along x: map(x,t) = x - (v t + a t^2, 0[, 0])   (maintests.jl:373-374: move v=1; accel a=2)"""
+    vv, aa = (v,) + (0.0,) * (D - 1), (a,) + (0.0,) * (D - 1)
     return Twin(AutoBody(lambda x, t: norm2(x - center) - radius, _shift(lambda t: v * t + a * t ** 2)),
-                G.Body(G.Sphere(center, radius), G.Translate(v=(v, 0.0), a=(a, 0.0))))
+                G.Body(G.Sphere(center, radius), G.Translate(v=vv, a=aa)),
+                lambda Dn: B.Sphere(center, radius, Dn, map=B.translation(Dn, v=vv, a=aa)))
+
+
+def rotating_circle(center, radius, pivot, w, th0=0.0):
+    """2-D circle whose coordinates rotate about `pivot`: map(x,t) = R(w t + th0) (x - pivot), sdf centred at `center`"""
+    def rotate(x, t):
+        s, c = torch.sin(w * t + th0), torch.cos(w * t + th0)
+        e = x - pivot
+        return torch.stack([c * e[0] + s * e[1], -s * e[0] + c * e[1]])
+    return Twin(AutoBody(lambda x, t: norm2(x - center) - radius, rotate),
+                G.Body(G.Sphere(center, radius), G.Rotate2D(pivot, w, th0)),
+                lambda D: B.Sphere(center, radius, 2, map=B.rotation2d(pivot, w, th0)))
 
 
 def _plate(radius):

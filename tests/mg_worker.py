@@ -23,9 +23,10 @@ from waterlily_amd.body import AutoBody, norm2  # noqa: E402
 
 def main():
     case = sys.argv[1] if len(sys.argv) > 1 else "sphere_f32"
-    if "rccl" in case:   # the production transport (one GPU per rank; world size 1 on a 1-GPU box)
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+    if "rccl" in case:   # the production transport: one GPU per rank (world size 1 on a 1-GPU box)
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         wd.init_rccl()
     else:
         dist.init_process_group("gloo")
@@ -53,6 +54,8 @@ def main():
         perdir = (1,)
     g = (lambda i, t: 0.05 * t if i == 0 else 0.0) if "accel" in case else None
     kw = dict(nu=nu, body=body, T=T, exitBC=("exit" in case), perdir=perdir, g=g)
+    if "rccl" in case:
+        kw["device"] = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
     ref = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=None, **kw)
     slab = wd.Slab(rank, size, dims[2], ring=(2 in perdir))
     # "deep": keep every level a slab as long as the partition allows; default: replicate levels <= 2^21 cells

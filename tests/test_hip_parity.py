@@ -601,6 +601,77 @@ def test_geometry_matches_oracle(geometry, T):
 
 
 @pytest.mark.parametrize("T", TYPES)
+def test_native_measure_matches_oracle(T):
+    """The hand-written measure! kernels (csrc/wl_measure.h: parametric body = closed-form sdf family + affine map)
+    against the closed-form geometry oracle: mu0, mu1, V (after BC!), sigma, the band-cell list and the pressure-force
+    band; a second measure! at a later time must leave no trace of the first (rows the body has left are rewritten
+    with (1,0,0)); the body-free row flags must mark every row that carries a non-trivial coefficient."""
+    m = 32
+    cases = [((m, m, m), bodies.sphere(m / 2 - 1, m / 8), (0.0,)), ((m, m, m), bodies.torus(m / 2, m / 4, m / 16), (0.0,)),
+             ((48, 32), bodies.sphere(15.0, 4.0), (0.0,)),
+             ((48, 32), bodies.moving_circle(14.0, 6.0, v=3.0, a=2.0), (0.0, 0.5, 2.5)),
+             ((40, 40), bodies.rotating_circle(9.0, 5.0, 20.0, 0.4, 1.0), (0.0, 1.7)),
+             ((m, m, m), bodies.moving_circle(12.0, 4.0, a=2.0, D=3), (0.3, 1.2))]
+    eps = geom_tol(T)
+    for dims, tw, times in cases:
+        D = len(dims)
+        ubc = (1.0,) + (0.0,) * (D - 1)
+        so = O.Simulation(dims, ubc, 8.0, body=tw.oracle, T=T)
+        sh = S.Simulation(dims, ubc, 8.0, body=tw.native(D), T=T)          # geometry="device": native kernels
+        for t in times:
+            O.measure(so, t)
+            S.measure(sh, t)
+            for k in ("mu0", "mu1", "V"):
+                w = getattr(so.flow, k)
+                assert np.abs(S.to_host(getattr(sh.flow, k)).astype(np.float64) - w).max() <= eps * max(1.0, np.abs(w).max()), (k, dims, t)
+            ins = O.inside(so.flow.sigma)
+            assert np.abs(S.to_host(sh.flow.sigma)[ins].astype(np.float64) - so.flow.sigma[ins]).max() <= eps * np.abs(so.flow.sigma).max()
+            # band cells: exactly the cells with sigma^2 < 9, ascending
+            sg = so.flow.sigma
+            want = np.flatnonzero(np.ravel((sg * sg < T(9)) & _inside_mask(sg.shape), order="F"))
+            got = sh.flow._band_cells[1].cpu().numpy()
+            if not np.array_equal(got, want):                           # sigma within 1 ulp of 3: membership may flip
+                assert len(np.setxor1d(got, want)) <= 2
+            # pressure-force band (nds, Metrics.jl:84-87) through wl_body_nds
+            so.flow.p[...] = rnd(so.flow.p.shape, T, 5)
+            S.upload(sh.flow.p, so.flow.p)
+            so.flow.dt[:] = [t, 0.25]                                    # time(flow) = t on both sides
+            sh.flow.dt[:] = [t, 0.25]
+            sh._band = None
+            fo, fh = O.pressure_force(so), S.pressure_force(sh)
+            assert np.allclose(fo, fh, rtol=1e-4 if T == np.float32 else 1e-10, atol=1e-5 if T == np.float32 else 1e-11), (dims, t)
+    # a moving native body steps like the oracle's (remeasure every step)
+    radius = 8
+    tw = bodies.moving_circle(2.0 * radius, radius, a=2.0)
+    so = O.Simulation((32, 32), (0, 0), radius, U=1, body=tw.oracle, nu=radius / 250, T=T)
+    sh = S.Simulation((32, 32), (0, 0), radius, U=1, body=tw.native(2), nu=radius / 250, T=T)
+    for _ in range(3):
+        O.sim_step(so)
+        S.sim_step(sh)
+    assert so.pois.n == sh.pois.n and sh.pois.n[:2] == [2, 1]
+    same(sh.flow.u, so.flow.u, exact=False, tol=50 * rtol(T))
+    # the body-free row flags the native path derives from its touched rows: BDIM! with them == BDIM! without (option 3)
+    runs = []
+    for on in (1, 0):
+        S.set_option(3, on)
+        try:
+            s3 = S.Simulation((m, m, m), (1.0, 0.0, 0.0), 8.0, body=bodies.moving_circle(12.0, 4.0, v=1.0, D=3).native(3), nu=0.05, T=T)
+            for _ in range(3):
+                S.sim_step(s3)
+        finally:
+            S.set_option(3, 1)
+        runs.append(s3)
+    assert runs[0].pois.n == runs[1].pois.n
+    assert torch.equal(runs[0].flow.u, runs[1].flow.u) and torch.equal(runs[0].flow.p, runs[1].flow.p)
+
+
+def _inside_mask(shape):
+    m = np.zeros(shape, bool)
+    m[tuple(slice(1, n - 1) for n in shape)] = True
+    return m
+
+
+@pytest.mark.parametrize("T", TYPES)
 def test_noncubic_partial_tiles(T):
     """Shapes that leave partially filled 64-wide (conv_diff) and 256-wide (vector stencil) tiles plus several tiles
     per row, like the reference's README example (96,64,64): operators bit-exact, a whole solve and steps close."""

@@ -111,6 +111,24 @@ def test_rccl_bootstrap_world1():
     check(out, "f32")
 
 
+def _device_count():
+    import torch
+    return torch.cuda.device_count()        # (does not initialise the GPU in this process)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["sphere_rccl_deep_f32", "sphere_rccl_zper_deep_f32"])
+def test_rccl_two_devices(case):
+    """The production transport between two REAL devices: ncclSend/ncclRecv halo planes on the comm stream (split
+    communicator), ncclAllReduce'd dot products, ncclAllGather hand-over to the replicated coarse levels -- must
+    reproduce the undecomposed run exactly like the host-transport twin.  Needs two GPUs: skipped on a 1-GPU box."""
+    if _device_count() < 2:
+        pytest.skip("needs 2 GPUs (one per rank)")
+    out = run_workers("mg_worker.py", 2, case)
+    assert out["overlapped"] > 0
+    check(out, "f32")
+
+
 @pytest.mark.gpu
 def test_bench_multirank_path():
     """bench.py's N>1 code path (slab set-up, timing reduction, JSON line) with 2 ranks sharing the GPU over gloo."""

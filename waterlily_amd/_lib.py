@@ -37,6 +37,14 @@ class FlowDesc(C.Structure):
         ("nu", C.c_double), ("exitBC", C.c_int32), ("perdir_mask", C.c_int32)]
 
 
+class BodyDesc(C.Structure):
+    """wl_body_desc (include/wlhip.h): a parametric body at one instant"""
+    _fields_ = [("family", C.c_int32), ("identity_map", C.c_int32), ("p", C.c_double * 8), ("A", C.c_double * 9),
+                ("b", C.c_double * 3), ("dA", C.c_double * 9), ("db", C.c_double * 3), ("Ainv", C.c_double * 9)]
+
+
+WL_BODY_SPHERE, WL_BODY_TORUS = 0, 1
+
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
@@ -122,6 +130,9 @@ def lib() -> C.CDLL:
         "wl_flow_create": (i, [C.POINTER(vp), i, C.POINTER(FlowDesc)]),
         "wl_flow_destroy": (i, [vp]),
         "wl_flow_update": (i, [vp]),
+        "wl_measure_rows": (i, [vp, C.POINTER(BodyDesc), d, C.POINTER(i64)]),
+        "wl_measure_fill": (i, [vp, C.POINTER(BodyDesc), d, vp]),
+        "wl_body_nds": (i, [gp, C.POINTER(BodyDesc), vp, i64, vp]),
         "wl_project": (i, [vp, vp, d, d, ip]),
         "wl_mom_step": (i, [vp, vp, d, dp, dp, dp, dp, ip]),
         "wl_metric": (i, [i, gp, i, vp, vp, i, dp, dp]),
@@ -140,7 +151,7 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.wl_abi_version() != 3:
+    if L.wl_abi_version() != 4:
         raise WlError("libwlhip.so ABI version mismatch; rebuild it")
     _lib = L
     return L

@@ -19,8 +19,8 @@ from typing import Callable, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-__all__ = ["AutoBody", "NoBody", "measure", "sdf", "kern", "kern0", "kern1", "mu0", "mu1", "norm2",
-           "measure_fields", "measure_fields_into", "nds_band"]
+__all__ = ["AutoBody", "NoBody", "Sphere", "Torus", "AffineMap", "translation", "rotation2d", "measure", "sdf", "kern",
+           "kern0", "kern1", "mu0", "mu1", "norm2", "measure_fields", "measure_fields_into", "nds_band"]
 
 
 def norm2(x: torch.Tensor) -> torch.Tensor:
@@ -65,6 +65,120 @@ class AutoBody:
 
     def __sub__(a, b: "AutoBody") -> "AutoBody":
         return a & (-b)
+
+
+# --- parametric bodies: closed-form sdf family + affine map, measured by the HIP kernels of csrc/wl_measure.h --------
+class AffineMap:
+    """map(x,t) = A(t) x + b(t) with its exact time derivative (what ForwardDiff.derivative gives the reference,
+    AutoBody.jl:129): `coeffs(t)` returns numpy (A (D,D), b (D,), dA/dt, db/dt)."""
+
+    def __init__(self, coeffs: Callable):
+        self.coeffs = coeffs
+
+    def __call__(self, x, t):   # the torch closure of the same map (generic / host path)
+        A, b, _, _ = self.coeffs_torch(x, t)
+        return A @ x + b[:, None]
+
+    def coeffs_torch(self, x, t):
+        raise NotImplementedError
+
+
+class _PolyTranslation(AffineMap):
+    """xi = x - (s0 + v t + a t^2): `move` (v=(1,0)) and `accel` (a=(2,0)) of maintests.jl:373-374"""
+
+    def __init__(self, D, v=0.0, a=0.0, s0=0.0):
+        self.D = D
+        self.v, self.a, self.s0 = (np.broadcast_to(np.asarray(q, dtype=np.float64), (D,)).copy() for q in (v, a, s0))
+
+    def coeffs(self, t):
+        I, Z = np.eye(self.D), np.zeros((self.D, self.D))
+        return I, -(self.s0 + self.v * t + self.a * t * t), Z, -(self.v + 2 * self.a * t)
+
+    def __call__(self, x, t):
+        cols = [torch.as_tensor(float(self.s0[i]), dtype=x.dtype, device=x.device) + float(self.v[i]) * t + float(self.a[i]) * t * t
+                for i in range(self.D)]
+        return x - torch.stack(cols)[:, None]
+
+
+def translation(D, v=0.0, a=0.0, s0=0.0) -> AffineMap:
+    return _PolyTranslation(D, v, a, s0)
+
+
+class _Rotation2D(AffineMap):
+    """xi = R(theta) (x - c), R = [c s; -s c], theta = w t + th0 (maintests.jl:376-379)"""
+
+    def __init__(self, center, w, th0=0.0):
+        self.c, self.w, self.th0 = float(center), float(w), float(th0)
+
+    def coeffs(self, t):
+        s, c = math.sin(self.w * t + self.th0), math.cos(self.w * t + self.th0)
+        R, dR = np.array([[c, s], [-s, c]]), np.array([[-s, c], [-c, -s]]) * self.w
+        cc = np.full(2, self.c)
+        return R, -R @ cc, dR, -dR @ cc
+
+    def __call__(self, x, t):
+        s, c = torch.sin(self.w * t + self.th0), torch.cos(self.w * t + self.th0)
+        e = x - self.c
+        return torch.stack([c * e[0] + s * e[1], -s * e[0] + c * e[1]])
+
+
+def rotation2d(center, w, th0=0.0) -> AffineMap:
+    return _Rotation2D(center, w, th0)
+
+
+class ParametricBody(AutoBody):
+    """An AutoBody whose sdf is one of the library's closed-form families and whose map (if any) is affine: besides the
+    torch closures (generic path: host geometry, other back ends) it can describe itself to the HIP `measure!` kernel."""
+    family = -1
+
+    def __init__(self, sdf_closure, params, map: Optional[AffineMap] = None):
+        super().__init__(sdf_closure, map)
+        self.params, self.amap = [float(v) for v in params], map
+
+    def native_desc(self, t: float, D: int):
+        from ._lib import BodyDesc
+        d = BodyDesc()
+        d.family, d.identity_map = self.family, int(self.amap is None)
+        for q, v in enumerate(self.params):
+            d.p[q] = v
+        A, b, dA, db = (np.eye(D), np.zeros(D), np.zeros((D, D)), np.zeros(D)) if self.amap is None else self.amap.coeffs(float(t))
+        Ai = np.linalg.inv(A)
+        for name, M in (("A", A), ("dA", dA), ("Ainv", Ai)):
+            full = np.zeros((3, 3))
+            full[:D, :D] = M
+            getattr(d, name)[:] = list(full.ravel())
+        for name, vec in (("b", b), ("db", db)):
+            full = np.zeros(3)
+            full[:D] = vec
+            getattr(d, name)[:] = list(full)
+        return d
+
+
+class Sphere(ParametricBody):
+    """sqrt(sum(abs2, x .- center)) - radius: circle (2-D) / sphere (3-D) of README.md:41-44,118-120.  `center`: a
+    scalar (every axis) or one value per axis."""
+    family = 0
+
+    def __init__(self, center, radius, D: int, map: Optional[AffineMap] = None):
+        c = np.broadcast_to(np.asarray(center, dtype=np.float64), (D,)).copy()
+        cl = [float(v) for v in c]
+
+        def sdf_closure(x, t):
+            return torch.sqrt(sum((x[i] - cl[i]) ** 2 for i in range(D))) - radius
+        super().__init__(sdf_closure, list(np.concatenate([c, np.zeros(3 - D)])) + [radius], map)
+
+
+class Torus(ParametricBody):
+    """norm((x1-c1, norm((x2-c2, x3-c3)) - R)) - r: the "donut" """
+    family = 1
+
+    def __init__(self, center, R, r, map: Optional[AffineMap] = None):
+        c = [float(v) for v in np.broadcast_to(np.asarray(center, dtype=np.float64), (3,))]
+
+        def sdf_closure(x, t):
+            q = torch.sqrt((x[1] - c[1]) ** 2 + (x[2] - c[2]) ** 2) - R
+            return torch.sqrt((x[0] - c[0]) ** 2 + q ** 2) - r
+        super().__init__(sdf_closure, c + [R, r], map)
 
 
 def _as_points(x) -> Tuple[torch.Tensor, bool]:

@@ -6,6 +6,7 @@
 
 #include "wl_ops.h"
 #include "wl_coarse.h"
+#include "wl_measure.h"
 
 namespace wl {
 
@@ -34,11 +35,15 @@ struct RcclComm : Comm {
         // order: my upper planes go up and fill the lower halo of peer_hi, whose first receive from me is its recv_lo, ...
         // (with a 2-rank ring both peers are the same rank: k-th send must meet the k-th receive of that peer)
         ncclComm_t h = nch ? nch : nc;
-        if (shi) ncclSend(shi, bytes, ncclChar, phi, h, ctx().stream);
-        if (rlo) ncclRecv(rlo, bytes, ncclChar, plo, h, ctx().stream);
-        if (slo) ncclSend(slo, bytes, ncclChar, plo, h, ctx().stream);
-        if (rhi) ncclRecv(rhi, bytes, ncclChar, phi, h, ctx().stream);
-        return chk(ncclGroupEnd(), "groupEnd(sendrecv)");
+        // every call is checked; on an error the group is still closed (an open group would swallow every later call)
+        if (!rc && shi) rc = chk(ncclSend(shi, bytes, ncclChar, phi, h, ctx().stream), "send(up)");
+        if (!rc && rlo) rc = chk(ncclRecv(rlo, bytes, ncclChar, plo, h, ctx().stream), "recv(from below)");
+        if (!rc && slo) rc = chk(ncclSend(slo, bytes, ncclChar, plo, h, ctx().stream), "send(down)");
+        if (!rc && rhi) rc = chk(ncclRecv(rhi, bytes, ncclChar, phi, h, ctx().stream), "recv(from above)");
+        const std::string first = ctx().err;
+        const int rce = chk(ncclGroupEnd(), "groupEnd(sendrecv)");
+        if (rc) { ctx().err = first; return rc; }
+        return rce;
     }
     int allgather(void *buf, size_t bytes) override {
         return chk(ncclAllGather((const char *)buf + (size_t)rank * bytes, buf, bytes, ncclChar, nc, ctx().stream), "allgather");
@@ -222,6 +227,12 @@ struct wl_flow {
     int *busy = nullptr;                // compact list of the busy interior rows (j + n1*k), device
     int nbusy = 0;
     size_t busy_cap = 0;
+    // native measure! (wl_measure.h): per-row band counts / offsets, rows touched by this and by the previous measure!
+    int *rowcount = nullptr;
+    long *rowoff = nullptr;
+    unsigned char *touched = nullptr, *prev = nullptr;
+    bool prev_valid = false;            // `prev` describes the arrays' current content (else: rewrite every row)
+    long nband = -1;                    // result of the last wl_measure_rows (-1: none pending)
 };
 
 template <class T> static LevelT<T> lvl(const wl_mg *m, int l) {
@@ -320,27 +331,35 @@ template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, in
 // project!  src/Flow.jl:137-145
 // exchange_u (z-slab runs, mom_step!): the 1-plane halo exchange of u that div needs (it reads u[I+dz]) is issued here on
 // the comm stream; x*=dt and div on all owned planes but the last run while it is in flight.
-template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double dt_, double w, int *n_iter, bool exchange_u = false) {
+// head_done: `x .*= dt` of this call was already applied (chained onto the previous projection's `x ./= dt`);
+// tail_then: instead of this call's own `x ./= dt` pass, run that and the NEXT projection's `x .*= dt'` as one stream.
+template <class T> static ScaleOp project_scale(double dt_, double w) {
+    const bool dbl = (w != 1.0);
+    return ScaleOp{dbl ? w * (double)(T)dt_ : (double)(T)dt_, false, dbl};
+}
+template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double dt_, double w, int *n_iter, bool exchange_u = false,
+                                                  bool head_done = false, const ScaleOp *tail_then = nullptr) {
     const G g = mkG(&a->d.g);
     LevelT<T> p = lvl<T>(b, 0);
-    const bool dbl = (w != 1.0);
-    const double dts = dbl ? w * (double)(T)dt_ : (double)(T)dt_;
+    const ScaleOp sc = project_scale<T>(dt_, w);
+    const double dts = sc.s;
+    const bool dbl = sc.dbl;
     const Range R = r_inside(g);
     if (exchange_u && D == 3 && g.dist && overlap_on() && R.hi[2] - R.lo[2] + 1 >= 2) {
         WL_TRY((halo_begin<T>(g, (T *)a->d.u, D, 1)));
-        WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
-        const int rc = op_div<T, D>(g, p.z, (const T *)a->d.u, R.lo[2], R.hi[2] - 1);
-        WL_TRY(halo_end());
+        int rc = head_done ? 0 : op_scale_all<T, D>(g, p.x, dts, false, dbl);
+        if (!rc) rc = op_div<T, D>(g, p.z, (const T *)a->d.u, R.lo[2], R.hi[2] - 1);
+        WL_TRY(halo_end());   // (always joined, also on an error above)
         if (rc) return rc;
         WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u, R.hi[2], R.hi[2])));
     } else {
         if (exchange_u) WL_TRY((halo_exchange<T>(g, (T *)a->d.u, D, 1)));
         WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u)));
-        WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
+        if (!head_done) WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
     }
     WL_TRY((mg_solve<T, D>(b, 1e-4, 32, n_iter)));
     WL_TRY((op_correct<T, D>(g, (T *)a->d.u, p.L, p.x, p.rowc)));
-    return op_scale_all<T, D>(g, p.x, dts, true, dbl);
+    return op_scale_all<T, D>(g, p.x, dts, true, dbl, tail_then);
 }
 
 // mom_step!  src/Flow.jl:153-169
@@ -359,13 +378,16 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true)));   // + exchange of f (overlapped)
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, u, u0, U, dt, a->sc.partials, a->sc.st)));
-    WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0], true)));   // + 1-plane exchange of u (overlapped with div)
+    // (the predictor's closing `x ./= dt` and the corrector's opening `x .*= 0.5dt` are ONE pass over x: nothing in between reads p)
+    const ScaleOp corr_head = project_scale<T>(dt, 0.5);
+    const bool chain = ctx().opt[14] != 0;
+    WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0], true, false, chain ? &corr_head : nullptr)));   // + 1-plane exchange of u (overlapped with div)
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     // corrector (:164-167); the 2-plane exchange of u is issued inside op_conv_diff (overlapped with its inner planes)
     WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr, nullptr, true)));
     WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
-    WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true)));
+    WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true, chain)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
     // push!(a.dt, CFL(a)) (:168); the end-of-step 2-plane exchange of u is issued inside (overlapped with the kernel)
     WL_TRY((op_cfl<T, D>(g, (T *)d.sigma, u, d.nu, a->sc.partials, a->sc.st, true)));
@@ -534,11 +556,9 @@ __global__ __launch_bounds__(256) void k_pforce(const T *p, const int64_t *idx, 
     if (threadIdx.x == 0)
         for (int c = 0; c < 3; ++c) partials[(long)c * gridDim.x + blockIdx.x] = acc[c];
 }
-template <class T, int D> static int flow_update(wl_flow *a) {
-    const G g = mkG(&a->d.g);
-    WL_TRY((op_rowflags<T, D>(g, (const T *)a->d.V, (const T *)a->d.mu0, (const T *)a->d.mu1, a->rowbuf, a->d.perdir_mask)));
+// compact the busy INTERIOR rows of a->rowbuf on the host (n1*n2 bytes; this runs once per measure!, not per step)
+static int flow_compact_busy(wl_flow *a, const G &g, int D) {
     a->rowfree = a->rowbuf;
-    // compact the busy INTERIOR rows on the host (n1*n2 bytes; this runs once per measure!, not per step)
     const size_t nrows = (size_t)g.n[1] * (size_t)(D > 2 ? g.n[2] : 1);
     std::vector<unsigned char> fl(nrows);
     WL_HIP(hipMemcpyAsync(fl.data(), a->rowbuf, nrows, hipMemcpyDeviceToHost, ctx().stream));
@@ -557,6 +577,82 @@ template <class T, int D> static int flow_update(wl_flow *a) {
     if (!list.empty()) WL_HIP(hipMemcpyAsync(a->busy, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, ctx().stream));
     WL_HIP(hipStreamSynchronize(ctx().stream));
     a->nbusy = (int)list.size();
+    return 0;
+}
+template <class T, int D> static int flow_update(wl_flow *a) {
+    const G g = mkG(&a->d.g);
+    WL_TRY((op_rowflags<T, D>(g, (const T *)a->d.V, (const T *)a->d.mu0, (const T *)a->d.mu1, a->rowbuf, a->d.perdir_mask)));
+    a->prev_valid = false;   // the arrays were written by someone else: the next native measure! rewrites every row
+    return flow_compact_busy(a, g, D);
+}
+static BodyDev body_dev(const wl_body_desc *b) {
+    BodyDev o;
+    o.family = b->family; o.ident = b->identity_map != 0;
+    for (int q = 0; q < 8; ++q) o.p[q] = b->p[q];
+    for (int q = 0; q < 9; ++q) { o.A[q] = b->A[q]; o.dA[q] = b->dA[q]; o.Ainv[q] = b->Ainv[q]; }
+    for (int q = 0; q < 3; ++q) { o.b[q] = b->b[q]; o.db[q] = b->db[q]; }
+    return o;
+}
+static int measure_alloc(wl_flow *a, size_t nrows) {
+    if (a->rowcount) return 0;
+    WL_HIP(hipMalloc((void **)&a->rowcount, nrows * sizeof(int)));
+    WL_HIP(hipMalloc((void **)&a->rowoff, (nrows + 1) * sizeof(long)));
+    WL_HIP(hipMalloc((void **)&a->touched, nrows));
+    WL_HIP(hipMalloc((void **)&a->prev, nrows));
+    return 0;
+}
+template <class T, int D> static int measure_rows(wl_flow *a, const wl_body_desc *body, double eps, int64_t *nband) {
+    const G g = mkG(&a->d.g);
+    const size_t nrows = (size_t)g.n[1] * (size_t)(D > 2 ? g.n[2] : 1);
+    WL_TRY(measure_alloc(a, nrows));
+    const BodyDev B = body_dev(body);
+    const T d2 = (T)((2 + eps) * (2 + eps));
+    {
+        Prof p(WL_K_MISC, g.cells());
+        hipLaunchKernelGGL((k_measure_rows<T, D>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ctx().stream, g, B, (T *)a->d.sigma, d2,
+                           a->rowcount, a->touched);
+        WL_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, ctx().stream, (const int *)a->rowcount, a->rowoff, (long)nrows);
+        WL_HIP(hipGetLastError());
+    }
+    long tot = 0;
+    WL_HIP(hipMemcpyAsync(&tot, a->rowoff + nrows, sizeof(long), hipMemcpyDeviceToHost, ctx().stream));
+    WL_HIP(hipStreamSynchronize(ctx().stream));
+    a->nband = tot;
+    *nband = tot;
+    return 0;
+}
+template <class T, int D> static int measure_fill(wl_flow *a, const wl_body_desc *body, double eps, int64_t *cand) {
+    const G g = mkG(&a->d.g);
+    const size_t nrows = (size_t)g.n[1] * (size_t)(D > 2 ? g.n[2] : 1);
+    const BodyDev B = body_dev(body);
+    const T d2 = (T)((2 + eps) * (2 + eps));
+    {
+        Prof p(WL_K_MISC, g.cells());
+        hipLaunchKernelGGL((k_measure_fill<T, D>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ctx().stream, g, B, (const T *)a->d.sigma, d2,
+                           (2 + eps) * (2 + eps), eps, (T *)a->d.mu0, (T *)a->d.mu1, (T *)a->d.V, (const unsigned char *)a->touched,
+                           (const unsigned char *)a->prev, !a->prev_valid, (const long *)a->rowoff, (long *)cand);
+        WL_HIP(hipGetLastError());
+    }
+    a->nband = -1;
+    // Body.jl:51-52, then what the host does after the reference's measure!: z-slab halos, body-free row flags
+    const double zero[3] = {0, 0, 0};
+    WL_TRY((op_bc_vec<T, D>(g, (T *)a->d.mu0, zero, 0, a->d.perdir_mask)));
+    WL_TRY((op_bc_vec<T, D>(g, (T *)a->d.V, zero, a->d.exitBC, a->d.perdir_mask)));
+    WL_TRY((halo_exchange<T>(g, (T *)a->d.mu0, D, 2)));
+    WL_TRY((halo_exchange<T>(g, (T *)a->d.V, D, 2)));
+    hipLaunchKernelGGL((k_rowflags_touched<D>), dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, ctx().stream, g,
+                       (const unsigned char *)a->touched, a->rowbuf, a->d.perdir_mask);
+    WL_HIP(hipGetLastError());
+    WL_HIP(hipMemcpyAsync(a->prev, a->touched, nrows, hipMemcpyDeviceToDevice, ctx().stream));
+    WL_TRY(flow_compact_busy(a, g, D));
+    a->prev_valid = true;
+    return 0;
+}
+static int check_body(const wl_body_desc *b, int D) {
+    if (!b) return fail(WL_E_ARG, "null body", __FILE__, __LINE__);
+    if (b->family != WL_BODY_SPHERE && b->family != WL_BODY_TORUS) return fail(WL_E_ARG, "unknown body family", __FILE__, __LINE__);
+    if (b->family == WL_BODY_TORUS && D != 3) return fail(WL_E_ARG, "the torus family needs D == 3", __FILE__, __LINE__);
     return 0;
 }
 // shared driver of the band reductions (pressure_force / viscous_force / pressure_moment)
@@ -898,12 +994,41 @@ int wl_flow_destroy(wl_flow *a) {
     a->sc.release();
     if (a->rowbuf) (void)hipFree(a->rowbuf);
     if (a->busy) (void)hipFree(a->busy);
+    if (a->rowcount) (void)hipFree(a->rowcount);
+    if (a->rowoff) (void)hipFree(a->rowoff);
+    if (a->touched) (void)hipFree(a->touched);
+    if (a->prev) (void)hipFree(a->prev);
     delete a;
     return 0;
 }
 int wl_flow_update(wl_flow *a) {
     if (!a) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);
     WL_DISPATCH(a->t, a->d.g.D, (flow_update<T, DD>(a)));
+}
+int wl_measure_rows(wl_flow *a, const wl_body_desc *body, double eps, int64_t *nband) {
+    if (!a || !nband) return fail(WL_E_ARG, "wl_measure_rows: null argument", __FILE__, __LINE__);
+    WL_TRY(check_body(body, a->d.g.D));
+    if (!(eps > 0)) return fail(WL_E_ARG, "wl_measure_rows: eps must be positive", __FILE__, __LINE__);
+    WL_DISPATCH(a->t, a->d.g.D, (measure_rows<T, DD>(a, body, eps, nband)));
+}
+int wl_measure_fill(wl_flow *a, const wl_body_desc *body, double eps, int64_t *cand_dev) {
+    if (!a) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);
+    WL_TRY(check_body(body, a->d.g.D));
+    if (a->nband < 0) return fail(WL_E_STATE, "wl_measure_fill: call wl_measure_rows first", __FILE__, __LINE__);
+    if (a->nband > 0 && !cand_dev) return fail(WL_E_ARG, "wl_measure_fill: null candidate buffer", __FILE__, __LINE__);
+    WL_DISPATCH(a->t, a->d.g.D, (measure_fill<T, DD>(a, body, eps, cand_dev)));
+}
+int wl_body_nds(const wl_grid *g, const wl_body_desc *body, const int64_t *cand_dev, int64_t n, double *nds_dev) {
+    WL_TRY(check_grid(g));
+    WL_TRY(check_body(body, g->D));
+    if (n <= 0) return 0;
+    if (!cand_dev || !nds_dev) return fail(WL_E_ARG, "wl_body_nds: null buffer", __FILE__, __LINE__);
+    const G gg = mkG(g);
+    const BodyDev B = body_dev(body);
+    Prof p(WL_K_PFORCE, n);
+    if (g->D == 3) hipLaunchKernelGGL((k_body_nds<3>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, gg, B, (const long *)cand_dev, (long)n, nds_dev);
+    else hipLaunchKernelGGL((k_body_nds<2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, gg, B, (const long *)cand_dev, (long)n, nds_dev);
+    return (int)hipGetLastError();
 }
 static int check_pair(const wl_flow *a, const wl_mg *b) {
     if (!a || !b) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);

@@ -527,12 +527,20 @@ _Pragma("unroll")
 // (w = 0.5 makes dt = w*dt a Float64, :138) so the operation is done in Float64 and rounded.
 // The array is one contiguous span [a, a + n_last*s_last) of the caller's allocation (ghosts and, in a padded layout,
 // the row padding included -- padding is never read by anything), so this is a flat 16-B-vector streaming kernel.
+// Two such operations can be chained in ONE pass (`two`): the second is applied to the rounded result of the first.
+// mom_step! uses it between its two projections: the predictor's `x ./= dt` (Flow.jl:144) and the corrector's
+// `x .*= 0.5dt` (:139) touch nothing in between that reads x, so they are one stream over x instead of two.
+struct ScaleOp { double s; bool divide, dbl; };
+template <class T> __device__ __forceinline__ T scale_one(T x, const ScaleOp &o) {
+    if (o.dbl) return o.divide ? (T)((double)x / o.s) : (T)((double)x * o.s);
+    return o.divide ? x / (T)o.s : x * (T)o.s;
+}
 template <class T>
-__global__ __launch_bounds__(256) void k_scale_flat(T *a, long n, long head, double s, T sT, bool divide, bool dbl) {
+__global__ __launch_bounds__(256) void k_scale_flat(T *a, long n, long head, ScaleOp o1, ScaleOp o2, bool two) {
     constexpr int V = 16 / sizeof(T);
     auto one = [&](T x) -> T {
-        if (dbl) return divide ? (T)((double)x / s) : (T)((double)x * s);
-        return divide ? x / sT : x * sT;
+        const T y = scale_one<T>(x, o1);
+        return two ? scale_one<T>(y, o2) : y;
     };
     const long nv = (n - head) / V;                 // whole aligned vectors after the unaligned head
     const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
@@ -547,7 +555,7 @@ __global__ __launch_bounds__(256) void k_scale_flat(T *a, long n, long head, dou
     if (t0 < V && tail < n) a[tail] = one(a[tail]);
 }
 template <class T, int D>
-int op_scale_all(const G &g, T *a, double s, bool divide, bool dbl) {
+int op_scale_all(const G &g, T *a, double s, bool divide, bool dbl, const ScaleOp *then = nullptr) {
     constexpr int V = 16 / sizeof(T);
     const long n = span(g);
     const long mis = (long)((reinterpret_cast<uintptr_t>(a) & 15) / sizeof(T));
@@ -558,7 +566,8 @@ int op_scale_all(const G &g, T *a, double s, bool divide, bool dbl) {
     if (nb > 8192) nb = 8192;
     if (nb < 1) nb = 1;
     Prof p(WL_K_SCALE, r_whole(g).count());
-    hipLaunchKernelGGL((k_scale_flat<T>), dim3((unsigned)nb), dim3(256), 0, ctx().stream, a, n, head, s, (T)s, divide, dbl);
+    const ScaleOp o1{s, divide, dbl};
+    hipLaunchKernelGGL((k_scale_flat<T>), dim3((unsigned)nb), dim3(256), 0, ctx().stream, a, n, head, o1, then ? *then : o1, then != nullptr);
     return (int)hipGetLastError();
 }
 
