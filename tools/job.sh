@@ -1,5 +1,4 @@
 set -e
-python -m pytest tests/test_hip_parity.py -q -m gpu -x -k "native or geometry or sphere_96 or c1_full" > gpurun_out/r2_t4.log 2>&1 || { tail -40 gpurun_out/r2_t4.log | cut -c1-400; exit 1; }
-tail -3 gpurun_out/r2_t4.log
-python tools/remeasure.py > gpurun_out/r2_remeasure.log 2>&1 || tail -20 gpurun_out/r2_remeasure.log
-cat gpurun_out/r2_remeasure.log
+export WL_PRESTEPS=12
+WL_CLASSES=pcg_mult_dot,pcg_update,pcg_direction,smooth,prolongate,residual,bdim python tools/sweep.py 512 16 4 8 16 > gpurun_out/r2_sweep_g16.log 2>&1; cat gpurun_out/r2_sweep_g16.log
+WL_CLASSES=pcg_mult_dot,pcg_update,pcg_direction,smooth,prolongate,residual python tools/sweep.py 256 16 4 8 16 > gpurun_out/r2_sweep_g16_256.log 2>&1; cat gpurun_out/r2_sweep_g16_256.log

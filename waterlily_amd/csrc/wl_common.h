@@ -41,7 +41,7 @@ struct Comm {
 };
 
 struct Ctx {
-    int opt[16] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1};   // wl_set_option
+    int opt[24] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 0, 0, 0, 0, 0, 0};   // wl_set_option
     Comm *comm = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -167,7 +167,8 @@ inline Range r_slice(const G &g, int i0, int j, int low0) {
 // ------------------------------------------------------------------------------------------ launch
 constexpr int WL_BX = 64;    // lanes along the fast axis = one wavefront
 constexpr int WL_BY = 4;     // rows per workgroup
-constexpr int WL_MAXB = 4096;  // grid cap (256 CUs x 16 workgroups): also the max number of reduction partials
+constexpr int WL_GRID = 4096;   // default grid size of the marching kernels (256 CUs x 16 workgroups)
+constexpr int WL_MAXB = 16384;  // hard grid cap = max number of reduction partials per value (scratch is sized for it)
 
 struct Tiling {
     int a, b, c;       // axis permutation: a = fast axis (first axis with extent > 1), c = marching axis
@@ -197,8 +198,8 @@ inline Tiling mk_tiling(const Range &R) {
     t.nta = (t.na + WL_BX - 1) / WL_BX;
     t.tpp = t.nta * ((t.nb + WL_BY - 1) / WL_BY);
     t.ptb = ((t.tpp + 7) / 8) * 8;              // multiple of 8 so the XCD un-swizzle applies (idle tail blocks)
-    if (t.ptb > WL_MAXB) t.ptb = WL_MAXB;
-    int want = WL_MAXB / t.ptb;                 // chunks that keep the grid <= WL_MAXB
+    if (t.ptb > WL_GRID) t.ptb = WL_GRID;
+    int want = WL_GRID / t.ptb;                 // chunks that keep the grid <= WL_GRID
     if (want < 1) want = 1;
     if (want > t.nc) want = t.nc;
     t.clen = (t.nc + want - 1) / want;

@@ -240,7 +240,7 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
     const int ntx = (g.n[0] - 2 + CD_BX - 1) / CD_BX, nty = (g.n[1] + CD_BY - 1) / CD_BY;
     const int tpp = ((ntx * nty + 7) / 8) * 8;  // padded to a multiple of 8 for the XCD mapping (idle tail tiles)
     const int nown = g.zhi - g.zlo + 1;
-    int want = WL_MAXB / tpp;
+    int want = WL_GRID / tpp;
     if (want < 1) want = 1;
     if (want > nown) want = nown;
     const int clen = (nown + want - 1) / want;

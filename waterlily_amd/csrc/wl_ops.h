@@ -665,7 +665,7 @@ int op_correct(const G &g, T *u, const T *L, const T *x, const T *rowc = nullptr
             const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + S7_BY - 1) / S7_BY;
             const int tpp = ((ntx * nty + 7) / 8) * 8;
             const int nown = R.hi[2] - R.lo[2] + 1;
-            int want = WL_MAXB / tpp;
+            int want = WL_GRID / tpp;
             if (want < 1) want = 1;
             if (want > nown) want = nown;
             const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;

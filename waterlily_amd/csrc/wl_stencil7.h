@@ -207,6 +207,7 @@ template <class T, class RKT> __device__ __forceinline__ T row_iD1(const RKT &rk
 // for ONE cell (the x neighbour of a wavefront's first / last lane).  NEED_ID: xf uses the row's iD constants.
 template <class T> struct SrcArray {          // e is an array (pcg!: eps, residual!: x, increment!: eps)
     static constexpr bool NEED_ID = false;
+    static constexpr int ROWS_AUTO = 2;        // rows per thread the default picks on big levels (measured at 512^3)
     using Raw = VecA<T>;
     const T *e;
     __device__ __forceinline__ Raw raw(long o, int, int, int) const { return VecA<T>::load(e + o); }
@@ -216,6 +217,7 @@ template <class T> struct SrcArray {          // e is an array (pcg!: eps, resid
 };
 template <class T> struct SrcJacobi {         // e = r*iD evaluated on the fly (Jacobi!, src/Poisson.jl:111)
     static constexpr bool NEED_ID = true;
+    static constexpr int ROWS_AUTO = 2;
     using Raw = VecA<T>;
     const T *r, *iD;
     int n0;
@@ -232,6 +234,7 @@ template <class T> struct SrcJacobi {         // e = r*iD evaluated on the fly (
 };
 template <class T> struct SrcProlong {        // e[I] = coarse x[down(I)] inside, 0 on ghosts (MultiLevelPoisson.jl:2,34)
     static constexpr bool NEED_ID = false;
+    static constexpr int ROWS_AUTO = 1;        // (two rows per thread measured 12 % slower for this source at 512^3)
     using Raw = VecA<T>;
     const T *cx;
     G C;            // coarse grid
@@ -467,10 +470,13 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, LD ld, ST st, const T *rowc
     }
 }
 
-// chunking of the marching axis: `tpp` workgroups per plane, `nown` planes; the grid is tpp*nchunk <= WL_MAXB (also the
+// chunking of the marching axis: `tpp` workgroups per plane, `nown` planes; the grid is tpp*nchunk <= the target (also the
 // number of reduction partials); cap > 0 limits the number of chunks (in-kernel partial sums want few partials)
-inline void chunking(int tpp, int nown, int cap, int *clen, int *nchunk) {
-    int want = WL_MAXB / tpp;
+inline void chunking(int tpp, int nown, int cap, int target_k, int *clen, int *nchunk) {
+    int target = target_k * 1024;                 // wl_set_option(16 / 17): grid size of the 7-point / streaming kernels in units of 1024 workgroups
+    if (target < 1024) target = 1024;
+    if (target > WL_MAXB) target = WL_MAXB;
+    int want = target / tpp;
     if (cap > 0 && cap < want) want = cap;
     if (want < 1) want = 1;
     if (want > nown) want = nown;
@@ -489,7 +495,7 @@ inline int launch_rowvec(int kclass, const G &g, LD ld, ST st, const T *rowc, do
     const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + 3) / 4;
     const int tpp = ((ntx * nty + 7) / 8) * 8;
     int clen, nchunk;
-    chunking(tpp, R.hi[2] - R.lo[2] + 1, ctx().opt[12], &clen, &nchunk);
+    chunking(tpp, R.hi[2] - R.lo[2] + 1, ctx().opt[12], ctx().opt[17], &clen, &nchunk);
     const int nblk = tpp * nchunk;
     if (nblk > WL_MAXB) return -1;
     if (np) *np = nblk;
@@ -567,7 +573,7 @@ inline int launch_stencil7_r(int kclass, const G &g, SRC src, const T *L, const 
     const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + S7_BY * R - 1) / (S7_BY * R);
     const int tpp = ((ntx * nty + 7) / 8) * 8;
     int clen, nchunk;
-    chunking(tpp, khi - klo + 1, ctx().opt[11], &clen, &nchunk);
+    chunking(tpp, khi - klo + 1, ctx().opt[11], ctx().opt[16], &clen, &nchunk);
     const int nblk = tpp * nchunk;
     if (nblk > WL_MAXB) return -1;   // plane too large for the partial buffer: caller falls back
     if (np) *np = nblk;
@@ -576,15 +582,15 @@ inline int launch_stencil7_r(int kclass, const G &g, SRC src, const T *L, const 
                        partials, ntx, tpp, nblk, clen, klo, khi, gate);
     return (int)hipGetLastError();
 }
-// rows per thread: wl_set_option(4, .): 1 or 2 forced; 0 (default) = 2 on levels of at least 2^24 interior cells whose
-// y extent is even (half the halo-row traffic; the larger register window costs occupancy, which only the big levels
-// can afford to trade), else 1
+// rows per thread: wl_set_option(4, .): 1 or 2 forced; 0 (default) = the source's preference (2 for array / Jacobi
+// sources, 1 for the prolongation source) on levels of at least 2^24 interior cells whose y extent is even (half the
+// halo-row traffic; the larger register window costs occupancy, which only the big levels can afford to trade), else 1
 template <class T, int NRED, class SRC, class EPI>
 inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, const T *rowc, const T *ea, const T *eb, EPI epi,
                            double *partials, int *np, Gate gate = Gate(), int kov_lo = 0, int kov_hi = -1) {
     const int want = ctx().opt[4];
     const bool even = ((g.n[1] - 2) % 2) == 0;
-    const bool two = even && (want == 2 || (want == 0 && r_inside(g).count() >= (1L << 24)));
+    const bool two = even && (want == 2 || (want == 0 && SRC::ROWS_AUTO == 2 && r_inside(g).count() >= (1L << 24)));
     if (two) return launch_stencil7_r<T, NRED, 2>(kclass, g, src, L, rowc, ea, eb, epi, partials, np, gate, kov_lo, kov_hi);
     return launch_stencil7_r<T, NRED, 1>(kclass, g, src, L, rowc, ea, eb, epi, partials, np, gate, kov_lo, kov_hi);
 }
