@@ -265,6 +265,8 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  *         finalize launch after every dot product
  * key 14: 1 = inside mom_step! the predictor's closing `x ./= dt` and the corrector's opening `x .*= 0.5dt`
  *         (Flow.jl:144,139) are one pass over x, each rounding kept (default), 0 = two passes
+ * key 18: 1 = conv_diff! evaluates each interior face flux once and shares it between the two cells (shared-flux LDS kernel
+ *         on the tiles / planes whose y and z faces are all interior) (default), 0 = every cell gathers its six fluxes
  * keys 16, 17: grid size of the 7-point / streaming vector kernels in units of 1024 workgroups (defaults 4 / 16: measured
  *         at 512^3, the streaming kernels gain 3-6 % from shorter z-chunks, the 7-point kernels do not)
  * keys 11, 12: > 0 = cap on the number of z-chunks of the 7-point / streaming vector kernels (measurement only) */

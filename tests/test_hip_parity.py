@@ -94,6 +94,26 @@ def test_conv_diff_bit_exact(T, Ng, perdir):
 
 
 @pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("Ng", [(200, 14, 12), (70, 22, 10), (130, 30, 7), (66, 10, 9)])
+@pytest.mark.parametrize("shared", [1, 0])
+def test_conv_diff_tile_paths_bit_exact(T, Ng, shared):
+    """The LDS conv_diff kernels on shapes that exercise every tile kind: several x tiles per row (first / last with the
+    domain's x-boundary faces, plain ones in between), partially filled last tiles, first / last tile rows and boundary
+    planes (the per-cell-gather kernel) around the interior block (the shared-flux kernel, wl_set_option(18)): bit-exact
+    against the oracle either way."""
+    S.set_option(18, shared)
+    try:
+        u = rnd(Ng + (3,), T, 8)
+        r, Phi = O.zeros(Ng + (3,), T), O.zeros(Ng, T)
+        O.conv_diff(r, u, Phi, nu=0.03)
+        ud, rd = field(u, 3), field(rnd(Ng + (3,), T, 9), 3)
+        S.conv_diff(rd, ud, nu=0.03)
+        same(rd, r)
+    finally:
+        S.set_option(18, 1)
+
+
+@pytest.mark.parametrize("T", TYPES)
 @pytest.mark.parametrize("Ng", SHAPES)
 def test_accelerate_bdim_scale_div_cfl(T, Ng):
     D = len(Ng)

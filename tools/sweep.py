@@ -34,7 +34,7 @@ for rep in range(2):
         row = []
         for nm in classes:
             _lib.check(L.wl_prof_reset())
-            _lib.check(L.wl_prof_select(names[nm], int(0.9 * size ** 3)))
+            _lib.check(L.wl_prof_select(names[nm], int(0.5 * size ** 3)))
             S.sim_step(sim, remeasure=False)
             nl, nc, ms = C.c_int64(), C.c_int64(), C.c_double()
             _lib.check(L.wl_prof_timed(C.byref(nl), C.byref(nc), C.byref(ms)))

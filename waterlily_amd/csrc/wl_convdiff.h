@@ -61,16 +61,16 @@ template <class T, bool FUSE, bool COPY>
 __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__ r, const T *__restrict__ u, T nu,
                                                            const T *u0, T *u0out, const T *__restrict__ V, T dt,
                                                            double a0, double a1, double a2, bool has_acc, int ntx,
-                                                           int tpp, int nblk, int clen) {
+                                                           int tpp, int nblk, int clen, int ty0, int ntile) {
     __shared__ T sm[3][3][CD_R][CD_W];  // [plane slot][component][row][col]
     const int tx = threadIdx.x & (CD_BX - 1), ty = threadIdx.x / CD_BX;
     const int b = blockIdx.x;
     const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);  // XCD-contiguous logical id
     const int ch = lb / tpp, pt = lb - ch * tpp;
-    const int i0 = 1 + CD_BX * (pt % ntx), j0 = CD_BY * (pt / ntx);
+    const int i0 = 1 + CD_BX * (pt % ntx), j0 = CD_BY * (ty0 + pt / ntx);   // ty0: first tile row of this launch
     const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2], nzg = g.nzg, kz0 = g.kz0;
     const int k0 = g.zlo + ch * clen, k1 = min(g.zhi + 1, k0 + clen);   // this chunk of the OWNED planes
-    if (k0 > g.zhi || j0 >= n1) return;  // uniform per workgroup (padding tiles)
+    if (k0 > g.zhi || j0 >= n1 || pt >= ntile) return;  // uniform per workgroup (padding tiles)
     const int i = i0 + tx, j = j0 + ty;
     const bool active = (i <= n0 - 2) && (j <= n1 - 1);
     const int ic = min(i, n0 - 1), jc = min(j, n1 - 1);
@@ -233,11 +233,228 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
     }
 }
 
-// host side: fast kernel on x in [1, n0-2], generic gather on the two x-ghost planes
+// ------------------------------------------------------------------------------------------------------------------
+// SHARED-FLUX form for the tiles and planes whose y and z faces are all interior faces (all but the first / last tile
+// row and the two planes next to each z boundary): the flux through a face is evaluated ONCE and used by both cells it
+// separates, as the reference's scatter form does (Flow.jl:46-47: r[I] += Phi[I]; r[I-d] -= Phi[I]) -- 9 flux
+// evaluations per cell instead of 15 (the kernel is VALU-bound: DESIGN.md section 4).
+//   * a thread evaluates the flux through the LOWER x, y and z face of its cell only;
+//   * its upper x flux is the lower x flux of lane+1 (wave shuffle), its upper y flux that of the thread one row up
+//     (through a small LDS flux buffer), its upper z flux that of its own next plane (carried, as before);
+//   * the fluxes of the tile's outermost upper faces -- x face i0+64 of the 4 rows, y face j0+4 of the 64 columns -- belong
+//     to no cell of the tile: each of the four wavefronts evaluates one more flux per plane for them (wavefronts 0..2 the
+//     y face of one component each, wavefront 3 the twelve x-face values), all operands from the LDS tile -- 10 evaluations
+//     per wavefront and plane, balanced (a fifth "edge" wavefront was measured first: 320-thread workgroups pack only 16
+//     working wavefronts on a CU instead of 24 and the kernel ran 70 % SLOWER than the per-cell gather form);
+//   * so that ONE barrier per plane still suffices, a cell is finished one iteration late: iteration k evaluates the
+//     lower fluxes of plane k and publishes them; iteration k+1 (after the plane barrier) collects the three upper fluxes
+//     of plane k and applies all six in the reference's order  ((((0 + Fx) - Fx') + Fy) - Fy') + Fz) - Fz'  .
+// x-boundary tiles (first / last tile of a row) stay on this path: the one boundary face of such a tile takes the
+// one-sided flux (GENX) and, for the upper boundary, the Float64 accumulation of Flow.jl:55.
+// Same arithmetic per flux, same order of the six updates => bit-identical to k_convdiff3 and to the oracle.
+template <class T> struct CdsShared {
+    T sm[3][3][CD_R][CD_W];            // [plane slot][component][row][col]
+    T fyb[2][3][CD_BY][CD_BX];         // lower-y fluxes of the tile's cells, by plane parity
+    T yedge[2][3][CD_BX];              // y flux through face j0+4
+    double xedge[2][3][CD_BY];         // x flux through face ie (Float64: the upper x boundary accumulates in it)
+};
+template <class T, bool FUSE, bool COPY, bool GENX>
+__device__ __forceinline__ void convdiff3s_tile(CdsShared<T> &S_, const G &g, T *__restrict__ r, const T *__restrict__ u, T nu, const T *u0,
+                                                T *u0out, const T *__restrict__ V, T dt, double a0, double a1, double a2, bool has_acc,
+                                                int i0, int j0, int ie, int k0, int k1) {
+    auto &sm = S_.sm; auto &fyb = S_.fyb; auto &yedge = S_.yedge; auto &xedge = S_.xedge;
+    const int tx = threadIdx.x & (CD_BX - 1), ty = threadIdx.x / CD_BX;
+    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
+    const bool xlow = GENX && (i0 == 1), xtop = GENX && (ie == n0 - 1);
+    const int i = i0 + tx, j = j0 + ty;
+    const bool active = (i <= n0 - 2);
+    const int ic = min(i, n0 - 1);
+    const long col = (long)ic + g.s[1] * (long)j;  // own column offset (clamped for idle lanes)
+    const long sz = g.s[2], sc = g.sc;
+
+    // halo duties of this thread: halo cell h1 = t, and h2 = t + 256 when < 288
+    int hl[2] = {0, 0};
+    long hg[2] = {0, 0};
+    int nh = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int h = (int)threadIdx.x + q * 256;
+        if (h < CD_HALO) {
+            int row, cl;
+            if (h < 4 * CD_W) { const int rr = h / CD_W; row = rr < 2 ? rr : rr + CD_BY; cl = h - rr * CD_W; }
+            else { const int qq = h - 4 * CD_W; row = CD_H + (qq >> 2); const int c4 = qq & 3; cl = c4 < 2 ? c4 : c4 + CD_BX; }
+            const int gx = min(max(i0 - CD_H + cl, 0), n0 - 1), gy = min(max(j0 - CD_H + row, 0), n1 - 1);
+            hl[nh] = row * CD_W + cl;
+            hg[nh] = (long)gx + g.s[1] * (long)gy;
+            ++nh;
+        }
+    }
+    const int own_l = (ty + CD_H) * CD_W + tx + CD_H;
+    auto clampk = [n2](int k) { return min(max(k, 0), n2 - 1); };
+    auto SM = [&](int slot, int c) -> T * { return &sm[slot][c][0][0]; };
+
+    // ---- prologue: register window k0-2..k0+1 of the own column, LDS planes k0-1 and k0
+    T W[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) W[c][q] = u[col + sz * clampk(k0 - 2 + q) + sc * c];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const int kk = clampk(k0 - 1 + pl);
+        const int slot = (k0 - 1 + pl + 3) % 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            SM(slot, c)[own_l] = W[c][1 + pl];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (q < nh) SM(slot, c)[hl[q]] = u[hg[q] + sz * kk + sc * c];
+        }
+    }
+    __syncthreads();
+
+    // carried state of cell k-1: its three lower fluxes (rounded to T like the reference's Phi scratch), BDIM operands
+    T cfx[3] = {0, 0, 0}, cfy[3] = {0, 0, 0}, cfz[3] = {0, 0, 0}, cu0[3] = {0, 0, 0}, cV[3] = {0, 0, 0};
+    bool carry = false;
+
+    for (int k = k0; k <= k1; ++k) {
+        const bool own = k < k1;
+        const int par = k & 1;
+        // ---- A. issue the global loads of the next planes first
+        T nxt[3], hv[2][3], e0[3] = {0, 0, 0}, eV[3] = {0, 0, 0};
+        const int kn = clampk(k + 2), kh = clampk(k + 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            nxt[c] = u[col + sz * kn + sc * c];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (q < nh) hv[q][c] = u[hg[q] + sz * kh + sc * c];
+            if (FUSE && own) { e0[c] = COPY ? W[c][2] : u0[col + sz * k + sc * c]; eV[c] = V[col + sz * k + sc * c]; }
+            if (COPY && own && active) u0out[col + sz * k + sc * c] = W[c][2];
+        }
+        // ---- B. lower fluxes of plane k
+        const int s1 = (k + 3) % 3, s0 = (k + 2) % 3;  // LDS slots of planes k and k-1
+        T fx[3], fy[3], fz[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const T *P = SM(s1, c) + own_l;  // plane k, component c, centred on the own cell
+            double ufz;
+            if (c == 0) ufz = (double)((T)(W[2][2] + SM(s1, 2)[own_l - 1]) * (T)0.5);
+            else if (c == 1) ufz = (double)((T)(W[2][2] + SM(s1, 2)[own_l - CD_W]) * (T)0.5);
+            else ufz = (double)((T)(W[2][2] + W[2][1]) * (T)0.5);
+            fz[c] = (T)cd_flux<T, false>(W[c][0], W[c][1], W[c][2], W[c][3], ufz, nu, false, false);
+            fx[c] = (T)0; fy[c] = (T)0;
+            if (!own) continue;               // (plane k1 only finishes cell k1-1: its z flux is all that is needed)
+            const T xm2 = P[-2], xm1 = P[-1], x0 = W[c][2], xp1 = P[1];
+            const T *PX = SM(s1, 0) + own_l;
+            double ufl;
+            if (c == 0) ufl = (double)((T)(PX[0] + PX[-1]) * (T)0.5);
+            else if (c == 1) ufl = (double)((T)(PX[0] + PX[-CD_W]) * (T)0.5);
+            else ufl = (double)((T)(PX[0] + W[0][1]) * (T)0.5);
+            fx[c] = (T)cd_flux<T, GENX>(xm2, xm1, x0, xp1, ufl, nu, xlow && (i == 1), false);
+            const T ym2 = P[-2 * CD_W], ym1 = P[-CD_W], yp1 = P[CD_W];
+            const T *PY = SM(s1, 1) + own_l;
+            double vfl;
+            if (c == 0) vfl = (double)((T)(PY[0] + PY[-1]) * (T)0.5);
+            else if (c == 1) vfl = (double)((T)(PY[0] + PY[-CD_W]) * (T)0.5);
+            else vfl = (double)((T)(PY[0] + W[1][1]) * (T)0.5);
+            fy[c] = (T)cd_flux<T, false>(ym2, ym1, x0, yp1, vfl, nu, false, false);
+            fyb[par][c][ty][tx] = fy[c];
+        }
+        // ---- B'. the tile's outermost upper faces, one extra evaluation per wavefront (all operands from LDS):
+        //      wavefronts 0..2: y face j0+4 of column tx for component ty; wavefront 3 (lanes 0..11): x face ie of row lane/3
+        if (own) {
+            if (ty < 3) {
+                const int c = ty;
+                const int el = (CD_BY + CD_H) * CD_W + tx + CD_H;     // LDS offset of cell (i0+tx, j0+4)
+                const T *P = SM(s1, c) + el;
+                const T *PY = SM(s1, 1) + el;
+                double vf;
+                if (c == 0) vf = (double)((T)(PY[0] + PY[-1]) * (T)0.5);
+                else if (c == 1) vf = (double)((T)(PY[0] + PY[-CD_W]) * (T)0.5);
+                else vf = (double)((T)(PY[0] + SM(s0, 1)[el]) * (T)0.5);
+                yedge[par][c][tx] = (T)cd_flux<T, false>(P[-2 * CD_W], P[-CD_W], P[0], P[CD_W], vf, nu, false, false);
+            } else if (tx < 3 * CD_BY) {
+                const int rr = tx / 3, c = tx - 3 * rr;
+                const int xl = (rr + CD_H) * CD_W + (ie - i0) + CD_H;   // LDS offset of cell (ie, j0+rr)
+                const T *P = SM(s1, c) + xl;
+                const T *PX = SM(s1, 0) + xl;
+                double uf;
+                if (c == 0) uf = (double)((T)(PX[0] + PX[-1]) * (T)0.5);
+                else if (c == 1) uf = (double)((T)(PX[0] + PX[-CD_W]) * (T)0.5);
+                else uf = (double)((T)(PX[0] + SM(s0, 0)[xl]) * (T)0.5);
+                const T fp1 = (ie + 1 <= n0 - 1) ? P[1] : P[0];          // (unused by the one-sided flux at the upper boundary)
+                xedge[par][c][rr] = cd_flux<T, GENX>(P[-2], P[-1], P[0], fp1, uf, nu, false, xtop);
+            }
+        }
+        // ---- C. finish cell k-1: upper fluxes = lower fluxes of the neighbours of plane k-1 (published last iteration)
+        if (carry) {
+            const int pp = par ^ 1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                T fxh = __shfl_down(cfx[c], 1, 64);
+                const double xe = xedge[pp][c][ty];
+                const bool lastc = (i + 1 == ie);
+                if (lastc) fxh = (T)xe;
+                const T fyh = (ty < CD_BY - 1) ? fyb[pp][c][ty + 1][tx] : yedge[pp][c][tx];
+                T v = (T)0 + cfx[c];
+                v = (GENX && xtop && lastc) ? (T)((double)v - xe) : v - fxh;
+                v = v + cfy[c];
+                v = v - fyh;
+                v = v + cfz[c];
+                v = v - fz[c];
+                if (active) {
+                    const long o = col + sz * (k - 1) + sc * c;
+                    if (FUSE) {
+                        if (has_acc) v = (T)((double)v + (c == 0 ? a0 : (c == 1 ? a1 : a2)));
+                        r[o] = (cu0[c] + dt * v) - cV[c];
+                    } else {
+                        r[o] = v;
+                    }
+                }
+            }
+        }
+        carry = own;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { cfx[c] = fx[c]; cfy[c] = fy[c]; cfz[c] = fz[c]; cu0[c] = e0[c]; cV[c] = eV[c]; }
+        // ---- D. rotate the register window, publish plane k+1 into its LDS slot
+        const int s2 = (k + 4) % 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            W[c][0] = W[c][1]; W[c][1] = W[c][2]; W[c][2] = W[c][3]; W[c][3] = nxt[c];
+            SM(s2, c)[own_l] = W[c][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (q < nh) SM(s2, c)[hl[q]] = hv[q][c];
+        }
+        __syncthreads();
+    }
+}
+// One launch covers every x tile of the interior tile rows; a tile holding a domain x-boundary face (first / last of a
+// row: uniform per workgroup) runs the copy of the plane loop with the one-sided flux variants (GENX), the others the plain one.
 template <class T, bool FUSE, bool COPY>
-int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u0out, const T *V, double dt_,
-                     const double *acc, bool has_acc) {
-    const int ntx = (g.n[0] - 2 + CD_BX - 1) / CD_BX, nty = (g.n[1] + CD_BY - 1) / CD_BY;
+__global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3s(G g, T *__restrict__ r, const T *__restrict__ u, T nu, const T *u0, T *u0out,
+                                                            const T *__restrict__ V, T dt, double a0, double a1, double a2, bool has_acc,
+                                                            int ntx, int tpp, int nblk, int clen, int ty0, int klo, int khi, int ntile) {
+    __shared__ CdsShared<T> S_;
+    const int b = blockIdx.x;
+    const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);  // XCD-contiguous logical id
+    const int ch = lb / tpp, pt = lb - ch * tpp;
+    const int n0 = g.n[0], n1 = g.n[1];
+    const int i0 = 1 + CD_BX * (pt % ntx), j0 = CD_BY * (ty0 + pt / ntx);
+    const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);      // this chunk of planes (all z faces interior)
+    if (k0 > khi || pt >= ntile || j0 + CD_BY - 1 > n1 - 3 || i0 > n0 - 2) return;   // uniform per workgroup (padding tiles)
+    const int ie = min(i0 + CD_BX, n0 - 1);       // the x face beyond the tile's last cell
+    if (i0 == 1 || ie == n0 - 1) convdiff3s_tile<T, FUSE, COPY, true>(S_, g, r, u, nu, u0, u0out, V, dt, a0, a1, a2, has_acc, i0, j0, ie, k0, k1);
+    else convdiff3s_tile<T, FUSE, COPY, false>(S_, g, r, u, nu, u0, u0out, V, dt, a0, a1, a2, has_acc, i0, j0, ie, k0, k1);
+}
+
+// host side.  One tile row = CD_BY rows of cells starting at j0 = CD_BY*ty; the shared-flux kernel takes the tile rows
+// whose cells have interior y faces only (2 <= j0, j0+CD_BY-1 <= n1-3) on the planes whose cells have interior z faces
+// only (global plane 2 .. nzg-3; every plane on a periodic ring of slabs); k_convdiff3 takes the first / last tile row
+// and the boundary planes; the two x-ghost planes go through the generic gather kernel (caller).
+template <class T, bool FUSE, bool COPY>
+int launch_convdiff3_old(const G &g, int ty0, int nty, T *r, const T *u, double nu_, const T *u0, T *u0out, const T *V, double dt_,
+                         const double (&a3)[3], bool has_acc) {
+    if (nty <= 0 || g.zhi < g.zlo) return 0;
+    const int ntx = (g.n[0] - 2 + CD_BX - 1) / CD_BX;
     const int tpp = ((ntx * nty + 7) / 8) * 8;  // padded to a multiple of 8 for the XCD mapping (idle tail tiles)
     const int nown = g.zhi - g.zlo + 1;
     int want = WL_GRID / tpp;
@@ -246,11 +463,45 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
     const int clen = (nown + want - 1) / want;
     const int nchunk = (nown + clen - 1) / clen;
     const int nblk = tpp * nchunk;
+    Prof p(WL_K_CONVDIFF, (long)g.n[0] * (long)(nty * CD_BY) * nown);
+    hipLaunchKernelGGL((k_convdiff3<T, FUSE, COPY>), dim3(nblk), dim3(CD_BX * CD_BY), 0, ctx().stream, g, r, u, (T)nu_, u0,
+                       u0out, V, (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen, ty0, ntx * nty);
+    return (int)hipGetLastError();
+}
+template <class T, bool FUSE, bool COPY>
+int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u0out, const T *V, double dt_,
+                     const double *acc, bool has_acc) {
     double a3[3] = {0, 0, 0};
     if (has_acc) for (int d = 0; d < 3; ++d) a3[d] = acc[d];
-    Prof p(WL_K_CONVDIFF, g.cells());
-    hipLaunchKernelGGL((k_convdiff3<T, FUSE, COPY>), dim3(nblk), dim3(CD_BX * CD_BY), 0, ctx().stream, g, r, u, (T)nu_, u0,
-                       u0out, V, (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen);
+    const int ntx = (g.n[0] - 2 + CD_BX - 1) / CD_BX, nty_all = (g.n[1] + CD_BY - 1) / CD_BY;
+    // tile rows with interior y faces only: ty in [tlo, thi]
+    const int tlo = 1, thi = (g.n[1] - 3 - (CD_BY - 1)) / CD_BY;      // CD_BY*ty + CD_BY-1 <= n1-3
+    // planes with interior z faces only, clipped to the owned planes
+    int klo = g.zlo, khi = g.zhi;
+    if (!g.zring) { klo = max(klo, 2 - g.kz0); khi = min(khi, g.nzg - 3 - g.kz0); }
+    const bool shared = ctx().opt[18] != 0 && thi >= tlo && khi >= klo;
+    if (!shared) return launch_convdiff3_old<T, FUSE, COPY>(g, 0, nty_all, r, u, nu_, u0, u0out, V, dt_, a3, has_acc);
+    // (1) boundary planes: every tile row, old kernel
+    if (klo > g.zlo) { G gb = g; gb.zhi = klo - 1; WL_TRY((launch_convdiff3_old<T, FUSE, COPY>(gb, 0, nty_all, r, u, nu_, u0, u0out, V, dt_, a3, has_acc))); }
+    if (khi < g.zhi) { G gb = g; gb.zlo = khi + 1; WL_TRY((launch_convdiff3_old<T, FUSE, COPY>(gb, 0, nty_all, r, u, nu_, u0, u0out, V, dt_, a3, has_acc))); }
+    // (2) interior planes, first / last tile rows: old kernel
+    G gi = g;
+    gi.zlo = klo; gi.zhi = khi;
+    WL_TRY((launch_convdiff3_old<T, FUSE, COPY>(gi, 0, tlo, r, u, nu_, u0, u0out, V, dt_, a3, has_acc)));
+    WL_TRY((launch_convdiff3_old<T, FUSE, COPY>(gi, thi + 1, nty_all - (thi + 1), r, u, nu_, u0, u0out, V, dt_, a3, has_acc)));
+    // (3) interior planes, interior tile rows: shared-flux kernel; x-boundary tiles in a launch of their own (GENX)
+    const int nty = thi - tlo + 1;
+    const int nown = khi - klo + 1;
+    const int ntile = ntx * nty;
+    const int tpp = ((ntile + 7) / 8) * 8;
+    int want = WL_GRID / tpp;
+    if (want < 1) want = 1;
+    if (want > nown) want = nown;
+    const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
+    const int nblk = tpp * nchunk;
+    Prof p(WL_K_CONVDIFF, (long)g.n[0] * (long)(nty * CD_BY) * nown);
+    hipLaunchKernelGGL((k_convdiff3s<T, FUSE, COPY>), dim3(nblk), dim3(CD_BX * CD_BY), 0, ctx().stream, g, r, u, (T)nu_, u0, u0out, V,
+                       (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen, tlo, klo, khi, ntile);
     return (int)hipGetLastError();
 }
 

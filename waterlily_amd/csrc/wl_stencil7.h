@@ -208,6 +208,7 @@ template <class T, class RKT> __device__ __forceinline__ T row_iD1(const RKT &rk
 template <class T> struct SrcArray {          // e is an array (pcg!: eps, residual!: x, increment!: eps)
     static constexpr bool NEED_ID = false;
     static constexpr int ROWS_AUTO = 2;        // rows per thread the default picks on big levels (measured at 512^3)
+    static constexpr bool EA_IS_RAW = false;   // the epilogue operand array `ea` is NOT the array raw() reads
     using Raw = VecA<T>;
     const T *e;
     __device__ __forceinline__ Raw raw(long o, int, int, int) const { return VecA<T>::load(e + o); }
@@ -218,6 +219,8 @@ template <class T> struct SrcArray {          // e is an array (pcg!: eps, resid
 template <class T> struct SrcJacobi {         // e = r*iD evaluated on the fly (Jacobi!, src/Poisson.jl:111)
     static constexpr bool NEED_ID = true;
     static constexpr int ROWS_AUTO = 2;
+    static constexpr bool EA_IS_RAW = true;    // the fused smoother's epilogue operand `a` is r itself: the raw centre vector
+                                               // of the window is handed over instead of loading r a second time
     using Raw = VecA<T>;
     const T *r, *iD;
     int n0;
@@ -235,6 +238,7 @@ template <class T> struct SrcJacobi {         // e = r*iD evaluated on the fly (
 template <class T> struct SrcProlong {        // e[I] = coarse x[down(I)] inside, 0 on ghosts (MultiLevelPoisson.jl:2,34)
     static constexpr bool NEED_ID = false;
     static constexpr int ROWS_AUTO = 1;        // (two rows per thread measured 12 % slower for this source at 512^3)
+    static constexpr bool EA_IS_RAW = false;
     using Raw = VecA<T>;
     const T *cx;
     G C;            // coarse grid
@@ -319,11 +323,13 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
 
         // ---- prologue: e of planes k0-1, k0 and the first in-flight set
         VA em[R], ec[R];
+        Raw rawc[R];                                        // raw own rows of plane k (kept only when the epilogue wants them)
         RowK<T> rk0[R];                                     // own-row constants of plane k
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             const long cq = col + q * sy;
             const Raw a = src.raw(cq + sz * (k0 - 1), i, jb + q, k0 - 1), c = src.raw(cq + sz * k0, i, jb + q, k0);
+            rawc[q] = c;
             const RowK<T> rkm = RK(q, k0 - 1);
             rk0[q] = RK(q, k0);
             em[q] = src.xf(a, rkm, cq + sz * (k0 - 1), i);
@@ -339,7 +345,8 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
             VA av[R], bv[R];
 #pragma unroll
             for (int q = 0; q < R; ++q) {
-                if (ea) av[q] = VA::load(ea + ok + q * sy);
+                if (SRC::EA_IS_RAW) av[q] = rawc[q];
+                else if (ea) av[q] = VA::load(ea + ok + q * sy);
                 if (eb) bv[q] = VA::load(eb + ok + q * sy);
             }
             request(nxt, kn);
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
                         s += em[q].v[v] * lz0.v[v] + ep[q].v[v] * lz1.v[v];
                         ae.v[v] = s;
                     }
-                    epi(o, i, jb + q, k, ae, ec[q], ea ? av[q] : ec[q], eb ? bv[q] : ec[q], rc, acc, pre);
+                    epi(o, i, jb + q, k, ae, ec[q], (ea || SRC::EA_IS_RAW) ? av[q] : ec[q], eb ? bv[q] : ec[q], rc, acc, pre);
                 }
 #pragma unroll
                 for (int q = 0; q < R; ++q) { em[q] = ec[q]; ec[q] = ep[q]; }
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
             if (fast) plane(std::true_type{}); else plane(std::false_type{});
             // ---- (4) the constants of plane k+1 (arrived: xf used them) become those of the next iteration's own plane
 #pragma unroll
-            for (int q = 0; q < R; ++q) rk0[q] = cur.rk[q];
+            for (int q = 0; q < R; ++q) { rk0[q] = cur.rk[q]; if (SRC::EA_IS_RAW) rawc[q] = cur.own[q]; }
         };
         for (int k = k0; k < k1; k += 2) {
             step(k, A, B);
