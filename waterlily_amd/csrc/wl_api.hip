@@ -271,13 +271,16 @@ template <class T, int D> static int mg_vcycle(wl_mg *m, int l, int *pcg_np = nu
     const bool fused = (m->permask == 0) && ctx().opt[1];   // periodic ghosts of eps are copies, not zeros: keep the two-pass form
     if (fused) WL_TRY((op_smooth_fused<T, D>(fine, fine.eps)));     // r' lives in the eps buffer until the way up
     else WL_TRY((op_jacobi<T, D>(fine, 1, m->permask)));
-    WL_TRY((op_restrict<T, D>(coarse.g, coarse.r, fine.g, fused ? fine.eps : fine.r)));
+    // fill!(coarse.x, 0) (MultiLevelPoisson.jl:75) rides in the restriction kernel where the level's ghost cells cannot
+    // hold anything but zero (no periodic copy, no halo exchange); otherwise it is a memset of the whole array
+    const bool zero_in_restrict = (m->permask == 0) && !coarse.g.dist && !fine.g.dist;
+    WL_TRY((op_restrict<T, D>(coarse.g, coarse.r, fine.g, fused ? fine.eps : fine.r, zero_in_restrict ? coarse.x : (T *)nullptr)));
     if (ctx().comm && ctx().comm->size > 1 && fine.g.dist && !coarse.g.dist) {
         // hand-over to the replicated coarse levels: every rank restricted the children it owns
         const int nzl = (fine.g.nzg - 2) / ctx().comm->size / 2;
         WL_TRY(ctx().comm->allgather(coarse.r + coarse.g.s[2], (size_t)nzl * coarse.g.s[2] * sizeof(T)));
     }
-    {
+    if (!zero_in_restrict) {
         Prof p(WL_K_MISC, coarse.g.cells());
         WL_HIP(hipMemsetAsync(coarse.x, 0, (size_t)span(coarse.g) * sizeof(T), ctx().stream));
     }

@@ -290,37 +290,39 @@ __global__ __launch_bounds__(WL_BX *WL_BY) void k_range_red(Tiling t, F f, doubl
     }
 }
 
-// Final stage: ONE workgroup reduces `np` partials per value in a fixed order, then runs the scalar
-// epilogue `fin(vals)` in thread 0 (device-resident solver scalars: no host round trip).
+// Final stage: ONE workgroup (1024 threads: up to 16384 partials per value, 128 KB, in ~16 loads per thread) reduces
+// `np` partials per value in a fixed order, then runs the scalar epilogue `fin(vals)` in thread 0 (device-resident
+// solver scalars: no host round trip).
+constexpr int WL_FIN_T = 1024;
 template <int NV, class FIN>
-__global__ __launch_bounds__(256) void k_finalize(const double *partials, int np, int op, double init, FIN fin) {
+__global__ __launch_bounds__(WL_FIN_T) void k_finalize(const double *partials, int np, int op, double init, FIN fin) {
     double acc[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         double a = init;
-        for (int i = threadIdx.x; i < np; i += 256) {
+        for (int i = threadIdx.x; i < np; i += WL_FIN_T) {
             double w = partials[(long)q * np + i];
             a = (op == RED_SUM) ? a + w : (w > a ? w : a);
         }
         acc[q] = a;
     }
-    block_red<NV>(acc, op);
+    block_red<NV, WL_FIN_T / 64>(acc, op);
     if (threadIdx.x == 0) fin(acc);
 }
 // distributed variant: local reduction -> red[], (all-reduce over ranks), then the scalar epilogue
 template <int NV>
-__global__ __launch_bounds__(256) void k_reduce_only(const double *partials, int np, int op, double init, double *red) {
+__global__ __launch_bounds__(WL_FIN_T) void k_reduce_only(const double *partials, int np, int op, double init, double *red) {
     double acc[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         double a = init;
-        for (int i = threadIdx.x; i < np; i += 256) {
+        for (int i = threadIdx.x; i < np; i += WL_FIN_T) {
             double w = partials[(long)q * np + i];
             a = (op == RED_SUM) ? a + w : (w > a ? w : a);
         }
         acc[q] = a;
     }
-    block_red<NV>(acc, op);
+    block_red<NV, WL_FIN_T / 64>(acc, op);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) red[q] = acc[q];
@@ -354,10 +356,10 @@ inline int launch_finalize(bool dist, const double *partials, int np, int op, do
     Prof p(WL_K_SCALAR, 0);
     Comm *cm = ctx().comm;
     if (!dist || !cm || cm->size == 1) {
-        hipLaunchKernelGGL((k_finalize<NV, FIN>), dim3(1), dim3(256), 0, ctx().stream, partials, np, op, init, fin);
+        hipLaunchKernelGGL((k_finalize<NV, FIN>), dim3(1), dim3(WL_FIN_T), 0, ctx().stream, partials, np, op, init, fin);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL((k_reduce_only<NV>), dim3(1), dim3(256), 0, ctx().stream, partials, np, op, init, red);
+    hipLaunchKernelGGL((k_reduce_only<NV>), dim3(1), dim3(WL_FIN_T), 0, ctx().stream, partials, np, op, init, red);
     int rc = cm->allreduce(red, NV, op);
     if (rc) return rc;
     hipLaunchKernelGGL((k_apply<FIN>), dim3(1), dim3(1), 0, ctx().stream, (const double *)red, fin);

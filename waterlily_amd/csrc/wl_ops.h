@@ -1251,6 +1251,22 @@ template <class T, int D>
 int op_L2(const LevelT<T> &p, double *partials, State *st, bool after_pcg = false) {
     const LevelT<T> q = p;
     int np = 0;
+    int rcv = -1;
+    if constexpr (D == 3) {
+        if (stencil7_ok<T>(p.g) && ctx().opt[5]) {   // 16-B streaming form; when the pcg! before it already produced r.r the
+            using VA = VecA<T>;                      // gate closes and every workgroup leaves at once
+            Gate gate;
+            if (after_pcg) { gate.active = &st->r2_valid; gate.inv = 1; }
+            rcv = launch_rowvec<T, 1, false>(WL_K_DOT, p.g,
+                [=] __device__(long o, int, int, const Pre &) { return VA::load(q.r + o); },
+                [=] __device__(long, int, int, int, const VA &rr, const auto &, double *acc, const Pre &) {
+_Pragma("unroll")
+                    for (int v = 0; v < VA::V; ++v) acc[0] += (double)rr.v[v] * (double)rr.v[v];
+                }, (const T *)nullptr, partials, &np, gate);
+            if (rcv > 0) return rcv;
+        }
+    }
+    if (rcv != 0)
     WL_TRY((launch_range_red<1>(WL_K_DOT, r_inside(p.g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
         if (after_pcg && st->r2_valid) return;
         const double v = (double)q.r[q.g.at(i, j, k)];
@@ -1321,10 +1337,13 @@ int coarse_L_finish(const G &ga, T *a, const G &gb, int permask) {
 }
 
 // restrict!  src/MultiLevelPoisson.jl:3-9,33 : coarse = SUM of the 2^D children (x fastest)
+// zero_x (optional, Vcycle!): the coarse solution array, zeroed for the same cells (`fill!(coarse.x, 0)`,
+// MultiLevelPoisson.jl:75: its ghost cells are never written on a non-periodic, undecomposed level, so they stay zero)
 template <class T, int D>
-int op_restrict(const G &ga, T *a, const G &gb, const T *b) {
+int op_restrict(const G &ga, T *a, const G &gb, const T *b, T *zero_x = nullptr) {
     const G A = ga, B = gb;
     return launch_range(WL_K_RESTRICT, r_children(ga, gb), [=] __device__(int i, int j, int k) {
+        if (zero_x) zero_x[A.at(i, j, k)] = (T)0;
         T s = 0;
         const int k0 = D > 2 ? 2 * A.kg(k) - 1 - B.kz0 : 0, k1 = D > 2 ? 2 * A.kg(k) - B.kz0 : 0;
         for (int kk = k0; kk <= k1; ++kk)

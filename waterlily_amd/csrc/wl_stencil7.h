@@ -90,6 +90,7 @@ struct Gate {
     double eps10 = 0.0;             // 10 eps(T)
     int f32 = 1;                    // the solver's element type is Float32 (scalars are rounded to it)
     int also_x = 0;                 // run also when only the deferred x update is owed (direction kernel)
+    int inv = 0;                    // kind 0: the body runs when *active == 0 instead
 };
 struct Pre { int act; double s0, s1; };
 // pcg!'s scalar logic, shared by the in-kernel form (gate_open) and the k_finalize epilogues of op_pcg
@@ -131,7 +132,7 @@ __device__ __forceinline__ bool gate_open(const Gate &gt, Pre &pre) {
     pre.act = 1; pre.s0 = 0.0; pre.s1 = 0.0;
     bool run = true;
     if (gt.kind == 0) {
-        if (gt.active) { pre.act = *gt.active; run = pre.act || (gt.also && *gt.also); }
+        if (gt.active) { pre.act = gt.inv ? !*gt.active : *gt.active; run = pre.act || (gt.also && *gt.also); }
         if (gt.s0) pre.s0 = *gt.s0;
         if (gt.s1) pre.s1 = *gt.s1;
         return run;
