@@ -114,7 +114,7 @@ def test_conv_diff_tile_paths_bit_exact(T, Ng, shared):
 
 
 @pytest.mark.parametrize("T", TYPES)
-@pytest.mark.parametrize("Ng", SHAPES)
+@pytest.mark.parametrize("Ng", SHAPES + [(18, 12, 10), (70, 9, 11)])     # (x extents that take the 16-B vector kernels too)
 def test_accelerate_bdim_scale_div_cfl(T, Ng):
     D = len(Ng)
     a_o = O.Flow(tuple(n - 2 for n in Ng), (1.0,) + (0.0,) * (D - 1), T=T, nu=0.01)

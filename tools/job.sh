@@ -1,13 +1,7 @@
 set -e
-python -m pytest tests -q -m gpu -x > gpurun_out/r2_t7.log 2>&1 || { tail -40 gpurun_out/r2_t7.log | cut -c1-400; exit 1; }
-tail -3 gpurun_out/r2_t7.log
-for cfg in "--size 512" "--size 256" "--size 512 --dtype f64" "--grid 1024 1024 512" "--size 512 --dtype f64 --body donut"; do
-  tag=$(echo $cfg | tr -d ' -')
-  python bench.py $cfg --steps 10 --warmup 5 --no-cpu-baseline > gpurun_out/r2_bench_$tag.json 2> gpurun_out/r2_bench_$tag.err || { tail -5 gpurun_out/r2_bench_$tag.err; }
-  python - <<PY
-import json
-d=json.load(open("gpurun_out/r2_bench_$tag.json"))
-r=d['roofline']; s=d.get('smoother') or {}
-print("$cfg", '| ms/step', round(d['ms_per_step'],2), 'MLUPS', round(d['value']), 'vcyc', d['config']['vcycles_per_solve'], '| dominant', r['kernel'], round(r['avg_launch_ms'],3), 'frac', round(r['frac'],3), '| smoother ms', round(s.get('avg_launch_ms',0),3), 'frac', round(s.get('frac',0),3))
-PY
-done
+python -m pytest tests/test_hip_parity.py tests/test_golden.py -q -m gpu -x > gpurun_out/r2_t8.log 2>&1 || { tail -40 gpurun_out/r2_t8.log | cut -c1-400; exit 1; }
+tail -3 gpurun_out/r2_t8.log
+export WL_PRESTEPS=12
+WL_CLASSES=div,cfl,scale,restrict,dot,correct python tools/sweep.py 512 5 2 > gpurun_out/r2_sweep_dc.log 2>&1; cat gpurun_out/r2_sweep_dc.log
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r2_bench9.json 2>/dev/null; python -c "
+import json; d=json.load(open('gpurun_out/r2_bench9.json')); print(d['ms_per_step'], d['value']); print(d['roofline']['per_class_ms_one_step'])"

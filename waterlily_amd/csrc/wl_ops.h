@@ -572,9 +572,52 @@ int op_scale_all(const G &g, T *a, double s, bool divide, bool dbl, const ScaleO
 }
 
 // @inside z[I] = div(I,u)  src/Flow.jl:11-17,139
+// operands of a face-difference pass (div, CFL): the V cells of the three components at o and their upper neighbours
+template <class T> struct FaceDat { VecA<T> x0, y0, y1, z0, z1; T xr; };
+template <class T> __device__ __forceinline__ FaceDat<T> face_load(const G &g, const T *u, long o, int j, int k) {
+    constexpr int V = VecA<T>::V;
+    FaceDat<T> d;
+    const int i = (int)(o - g.s[1] * j - g.s[2] * k);
+    d.x0 = VecA<T>::load(u + o);
+    d.xr = (T)0;
+    if ((threadIdx.x & 63) == 63 || i + V > g.n[0] - 2) d.xr = u[o + V];        // the cell beyond this lane's vector
+    d.y0 = VecA<T>::load(u + o + g.sc); d.y1 = VecA<T>::load(u + o + g.sc + g.s[1]);
+    d.z0 = VecA<T>::load(u + o + 2 * g.sc); d.z1 = VecA<T>::load(u + o + 2 * g.sc + g.s[2]);
+    return d;
+}
+// upper x neighbour of element v of the lane's vector: next element, next lane's first element, or the loaded cell
+template <class T> __device__ __forceinline__ void face_xup(const G &g, const FaceDat<T> &d, int i, T (&xu)[VecA<T>::V]) {
+    constexpr int V = VecA<T>::V;
+    T nxt = __shfl_down(d.x0.v[0], 1, 64);
+    if ((threadIdx.x & 63) == 63 || i + V > g.n[0] - 2) nxt = d.xr;
+#pragma unroll
+    for (int v = 0; v < V; ++v) xu[v] = (v == V - 1) ? nxt : d.x0.v[v == V - 1 ? v : v + 1];
+}
 template <class T, int D>
 int op_div(const G &g, T *z, const T *u, int klo = 0, int khi = -1) {   // [klo,khi]: optional local plane sub-range
     const G gg = g;
+    if constexpr (D == 3) {
+        if (stencil7_ok<T>(g) && ctx().opt[5]) {   // 16-B vector form (same sums in the same order)
+            using VA = VecA<T>;
+            const int rc = launch_rowvec<T, 0, false>(WL_K_DIV, g,
+                [=] __device__(long o, int j, int k, const Pre &) { return face_load<T>(gg, u, o, j, k); },
+                [=] __device__(long o, int i, int, int, const FaceDat<T> &d, const auto &, double *, const Pre &) {
+                    T xu[VA::V];
+                    face_xup<T>(gg, d, i, xu);
+                    VA out;
+_Pragma("unroll")
+                    for (int v = 0; v < VA::V; ++v) {
+                        T s = 0;
+                        s += xu[v] - d.x0.v[v];
+                        s += d.y1.v[v] - d.y0.v[v];
+                        s += d.z1.v[v] - d.z0.v[v];
+                        out.v[v] = s;
+                    }
+                    out.store(z + o);
+                }, (const T *)nullptr, nullptr, nullptr, Gate(), klo, khi);
+            if (rc >= 0) return rc;
+        }
+    }
     Range R = r_inside(g);
     if (khi >= klo) { R.lo[2] = klo > R.lo[2] ? klo : R.lo[2]; R.hi[2] = khi < R.hi[2] ? khi : R.hi[2]; }
     return launch_range(WL_K_DIV, R, [=] __device__(int i, int j, int k) {
@@ -723,7 +766,32 @@ _Pragma("unroll")
         np = n1 + n2;
     } else {
         if (exchange_u) WL_TRY((halo_exchange<T>(g, const_cast<T *>(u), D, 2)));
-        WL_TRY((launch_range_red<1>(WL_K_CFL, R, body, partials, RED_MAX, -1e300, &np)));
+        int rcv = -1;
+        if constexpr (D == 3) {
+            if (stencil7_ok<T>(g) && ctx().opt[5]) {   // 16-B vector form: same sums in the same order, max over the same cells
+                using VA = VecA<T>;
+                auto ld = [=] __device__(long o, int j, int k, const Pre &) { return face_load<T>(gg, u, o, j, k); };
+                auto st2 = [=] __device__(long o, int i, int, int, const FaceDat<T> &d, const auto &, double *acc, const Pre &) {
+                    T xu[VA::V];
+                    face_xup<T>(gg, d, i, xu);
+                    VA out;
+_Pragma("unroll")
+                    for (int v = 0; v < VA::V; ++v) {
+                        double s = 0;
+                        { const double a = (double)xu[v], b = -(double)d.x0.v[v]; s += (a > 0 ? a : 0.0) + (b > 0 ? b : 0.0); }
+                        { const double a = (double)d.y1.v[v], b = -(double)d.y0.v[v]; s += (a > 0 ? a : 0.0) + (b > 0 ? b : 0.0); }
+                        { const double a = (double)d.z1.v[v], b = -(double)d.z0.v[v]; s += (a > 0 ? a : 0.0) + (b > 0 ? b : 0.0); }
+                        const T sg = (T)s;
+                        out.v[v] = sg;
+                        acc[0] = (double)sg > acc[0] ? (double)sg : acc[0];
+                    }
+                    out.store(sigma + o);
+                };
+                rcv = launch_rowvec<T, 1, false, decltype(ld), decltype(st2), RED_MAX>(WL_K_CFL, g, ld, st2, (const T *)nullptr, partials, &np);
+                if (rcv > 0) return rcv;
+            }
+        }
+        if (rcv != 0) WL_TRY((launch_range_red<1>(WL_K_CFL, R, body, partials, RED_MAX, -1e300, &np)));
     }
     const T nu5 = (T)5 * (T)nu_;
     return launch_finalize<1>(g.dist, partials, np, RED_MAX, -1e300, st->red, [=] __device__(const double *v) {
@@ -1005,14 +1073,29 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     // workgroups that keeps the in-kernel sums cheap costs the streaming kernels more than the launches it saves
     // (512^3: +0.8 %; 256^3 and every coarser level: -2.8 %).
     const int tpp_v = D == 3 ? (((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 3) / 4) + 7) / 8 * 8 : 0;
+    // z-slab levels (round 2): the same mechanism with the all-reduce in between -- the producer's partials are summed by
+    // k_reduce_only, all-reduced over the ranks, and the consuming kernel's gate applies the scalar logic to that ONE value
+    // (Gate kind 1..3 with np = 1): per dot product reduce + ncclAllReduce instead of reduce + ncclAllReduce + k_apply.
+    const bool distr = p.g.dist && ctx().comm && ctx().comm->size > 1;
     const bool infin = vec && xdef && zrec && R.count() > 0 && tpp_v > 0 &&
-                       (ctx().opt[15] == 2 || (ctx().opt[15] == 1 && R.count() <= (1L << 25))) &&
-                       tpp_v <= 1024 && !(p.g.dist && ctx().comm && ctx().comm->size > 1);
+                       (distr ? ctx().opt[15] != 0
+                              : ((ctx().opt[15] == 2 || (ctx().opt[15] == 1 && R.count() <= (1L << 25))) && tpp_v <= 1024));
     struct CapGuard {   // the in-kernel sums want few partials: cap the number of z-chunks for the kernels of this call
         int o11, o12; bool on;
         CapGuard(bool on_, int cap) : o11(ctx().opt[11]), o12(ctx().opt[12]), on(on_) { if (on) { ctx().opt[11] = cap; ctx().opt[12] = cap; } }
         ~CapGuard() { if (on) { ctx().opt[11] = o11; ctx().opt[12] = o12; } }
-    } capguard(infin, infin ? (1024 / tpp_v > 0 ? 1024 / tpp_v : 1) : 0);
+    } capguard(infin && !distr, (infin && !distr) ? (1024 / tpp_v > 0 ? 1024 / tpp_v : 1) : 0);
+    // what the consuming gate sums: the producer's partials, or (z-slabs) the one all-reduced value
+    auto ready = [&](const double *&part, int &n) -> int {
+        if (!distr) return 0;
+        Prof pr(WL_K_SCALAR, 0);
+        hipLaunchKernelGGL((k_reduce_only<1>), dim3(1), dim3(WL_FIN_T), 0, ctx().stream, part, n, (int)RED_SUM, 0.0, st->red);
+        WL_HIP(hipGetLastError());
+        WL_TRY(ctx().comm->allreduce(st->red, 1, RED_SUM));
+        part = st->red;
+        n = 1;
+        return 0;
+    };
     double *P0 = partials, *PA = infin ? partials + WL_MAXB : partials, *PB = infin ? partials + 2 * WL_MAXB : partials;
     const int f32 = sizeof(T) == 4;
     const int n0 = p.g.n[0];
@@ -1062,7 +1145,11 @@ _Pragma("unroll")
                 exchanged = true;
                 Gate gate_mult;
                 if (!infin) gate_mult.active = &st->active;
-                else if (n == 1) { gate_mult.kind = 1; gate_mult.part = P0; gate_mult.np = np0; gate_mult.out = &st->slots[0]; cur = 0; }
+                else if (n == 1) {
+                    const double *gp = P0; int gn = np0;
+                    WL_TRY(ready(gp, gn));
+                    gate_mult.kind = 1; gate_mult.part = gp; gate_mult.np = gn; gate_mult.out = &st->slots[0]; cur = 0;
+                }
                 else { gate_mult.kind = 4; gate_mult.in = &st->slots[cur]; }
                 gate_mult.eps10 = (double)eps10; gate_mult.f32 = f32;
                 rcv = launch_stencil7_halo<T, 1>(WL_K_PCG_MULT, p.g, p.eps, SrcArray<T>{p.eps}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
@@ -1100,7 +1187,11 @@ _Pragma("unroll")
         int rvu = -1;
         Gate gate_upd;
         if (!infin) { gate_upd.active = &st->active; gate_upd.s0 = &st->alpha; }
-        else { gate_upd.kind = 2; gate_upd.part = PA; gate_upd.np = npA; gate_upd.in = &st->slots[cur]; gate_upd.out = &st->slots[cur ^ 1]; }
+        else {
+            const double *gp = PA; int gn = npA;
+            WL_TRY(ready(gp, gn));
+            gate_upd.kind = 2; gate_upd.part = gp; gate_upd.np = gn; gate_upd.in = &st->slots[cur]; gate_upd.out = &st->slots[cur ^ 1];
+        }
         gate_upd.eps10 = (double)eps10; gate_upd.f32 = f32;
         if (vec) {
             struct UD { VA r, z, x, e; };
@@ -1158,7 +1249,7 @@ _Pragma("unroll")
         if (infin) {
             if (last) {   // the one finalize of the call: finishes r.r (:135) and publishes the state for the host / L2
                 const int cs = cur;
-                WL_TRY((launch_finalize<1>(false, PB, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
+                WL_TRY((launch_finalize<1>(p.g.dist, PB, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
                     PcgS sl = st->slots[cs];
                     if (sl.active) {
                         sl.nupd += 1;
@@ -1190,7 +1281,11 @@ _Pragma("unroll")
         int rvd = -1;
         Gate gate_dir;
         if (!infin) { gate_dir.active = &st->active; gate_dir.also = xdef ? &st->xpend : nullptr; gate_dir.s0 = &st->alpha; gate_dir.s1 = &st->beta; }
-        else { gate_dir.kind = 3; gate_dir.part = PB; gate_dir.np = np; gate_dir.in = &st->slots[cur]; gate_dir.out = &st->slots[cur ^ 1]; gate_dir.also_x = 1; }
+        else {
+            const double *gp = PB; int gn = np;
+            WL_TRY(ready(gp, gn));
+            gate_dir.kind = 3; gate_dir.part = gp; gate_dir.np = gn; gate_dir.in = &st->slots[cur]; gate_dir.out = &st->slots[cur ^ 1]; gate_dir.also_x = 1;
+        }
         gate_dir.eps10 = (double)eps10; gate_dir.f32 = f32;
         if (vec) {
             struct DD { VA e, x, z; };

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
 // cells at element offset o and returns them; st(o, i, j, k, data, rk, acc, pre) consumes them one iteration later (the
 // loads of plane k+1 are in flight while plane k is computed and stored).  RK: hand the row constants to st.
 // Same row mapping as k_stencil7 with R = 1 (lane = V cells of a row, wavefront = row segment, workgroup = 4 rows).
-template <class T, int NRED, bool RK, class LD, class ST>
+template <class T, int NRED, bool RK, class LD, class ST, int OP = RED_SUM>
 __global__ __launch_bounds__(256) void k_rowvec(G g, LD ld, ST st, const T *rowc, double *partials, int ntx, int tpp, int nblk,
                                                 int clen, int klo, int khi, Gate gate) {
     constexpr int V = Vec16<T>::V;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, LD ld, ST st, const T *rowc
     const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);
     double acc[NRED > 0 ? NRED : 1];
 #pragma unroll
-    for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) acc[q] = 0.0;
+    for (int q = 0; q < (NRED > 0 ? NRED : 1); ++q) acc[q] = (OP == RED_MAX) ? -1e300 : 0.0;
     Pre pre;
     const bool run = gate_open(gate, pre);
     if (run && i <= g.n[0] - 2 && j <= g.n[1] - 2 && k0 < k1) {
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, LD ld, ST st, const T *rowc
         }
     }
     if (NRED > 0) {
-        block_red<(NRED > 0 ? NRED : 1), 4>(acc, RED_SUM);
+        block_red<(NRED > 0 ? NRED : 1), 4>(acc, OP);
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int q = 0; q < NRED; ++q) partials[(long)q * gridDim.x + blockIdx.x] = acc[q];
@@ -492,7 +492,7 @@ inline void chunking(int tpp, int nown, int cap, int target_k, int *clen, int *n
     *nchunk = (nown + *clen - 1) / *clen;
 }
 
-template <class T, int NRED, bool RK, class LD, class ST>
+template <class T, int NRED, bool RK, class LD, class ST, int OP = RED_SUM>
 inline int launch_rowvec(int kclass, const G &g, LD ld, ST st, const T *rowc, double *partials, int *np, Gate gate = Gate(),
                          int kov_lo = 0, int kov_hi = -1) {
     constexpr int V = Vec16<T>::V;
@@ -508,7 +508,7 @@ inline int launch_rowvec(int kclass, const G &g, LD ld, ST st, const T *rowc, do
     if (nblk > WL_MAXB) return -1;
     if (np) *np = nblk;
     Prof p(kclass, R.count());
-    hipLaunchKernelGGL((k_rowvec<T, NRED, RK, LD, ST>), dim3(nblk), dim3(256), 0, ctx().stream, g, ld, st, RK ? rowc : nullptr, partials,
+    hipLaunchKernelGGL((k_rowvec<T, NRED, RK, LD, ST, OP>), dim3(nblk), dim3(256), 0, ctx().stream, g, ld, st, RK ? rowc : nullptr, partials,
                        ntx, tpp, nblk, clen, R.lo[2], R.hi[2], gate);
     return (int)hipGetLastError();
 }
