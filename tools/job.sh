@@ -1,7 +1,6 @@
 set -e
-python -m pytest tests/test_hip_parity.py tests/test_golden.py -q -m gpu -x > gpurun_out/r2_t8.log 2>&1 || { tail -40 gpurun_out/r2_t8.log | cut -c1-400; exit 1; }
-tail -3 gpurun_out/r2_t8.log
+python -m pytest tests/test_hip_parity.py tests/test_golden.py tests/test_fullsize_properties.py -q -m gpu -x > gpurun_out/r2_t10.log 2>&1 || { tail -40 gpurun_out/r2_t10.log | cut -c1-600; exit 1; }
+tail -3 gpurun_out/r2_t10.log
+python tools/ab_step.py 512 19 4 > gpurun_out/r2_ab19.log 2>&1; cat gpurun_out/r2_ab19.log
 export WL_PRESTEPS=12
-WL_CLASSES=div,cfl,scale,restrict,dot,correct python tools/sweep.py 512 5 2 > gpurun_out/r2_sweep_dc.log 2>&1; cat gpurun_out/r2_sweep_dc.log
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r2_bench9.json 2>/dev/null; python -c "
-import json; d=json.load(open('gpurun_out/r2_bench9.json')); print(d['ms_per_step'], d['value']); print(d['roofline']['per_class_ms_one_step'])"
+WL_CLASSES=bc,conv_diff python tools/sweep.py 512 19 1 0 > gpurun_out/r2_sweep_19.log 2>&1; cat gpurun_out/r2_sweep_19.log

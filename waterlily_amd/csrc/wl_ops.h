@@ -82,17 +82,19 @@ int op_bc_vec(const G &g, T *a, const double *A, int saveexit, int permask) {
 // continue at the clamped source index, normal j -> the Dirichlet value A[i] (planes 1,2,N; N skipped when saving the
 // exit).  The walk ends on a cell no pass writes, so every thread reads only never-written cells: no ordering hazard.
 template <class T, int D>
-__global__ __launch_bounds__(256) void k_bc_vec_all(G g, T *a, T A0, T A1, T A2, int saveexit, int permask, long nthreads) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_bc_vec_all(G g, T *a, T A0, T A1, T A2, int saveexit, int permask, unsigned nthreads) {
+    // (32-bit index arithmetic: the ghost-cell count of any grid that fits this part is far below 2^31; a 64-bit
+    //  division costs ~4x a 32-bit one and this decode has eight of them)
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
     if (t >= nthreads) return;
     // thread -> (direction d, plane p in {0,1,n-1}, position in the plane, component c)
     const int ng[3] = {g.n[0], g.n[1], D > 2 ? g.nzg : 1};
-    long rem = t;
+    unsigned rem = t;
     int d = 0;
-    long per[3];
+    unsigned per[3];
     for (int q = 0; q < D; ++q) {
-        long cells = 3;
-        for (int e = 0; e < D; ++e) if (e != q) cells *= (e == 2 ? (long)(g.zhi - g.zlo + 1) : (long)g.n[e]);
+        unsigned cells = 3;
+        for (int e = 0; e < D; ++e) if (e != q) cells *= (e == 2 ? (unsigned)(g.zhi - g.zlo + 1) : (unsigned)g.n[e]);
         per[q] = cells * D;
     }
     while (d < D - 1 && rem >= per[d]) { rem -= per[d]; ++d; }
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void k_bc_vec_all(G g, T *a, T A0, T A1, T A2,
     int idx[3] = {0, 0, 0};   // GLOBAL indices
     for (int e = 0; e < D; ++e) {
         if (e == d) { idx[e] = pl == 0 ? 0 : (pl == 1 ? 1 : ng[e] - 1); continue; }
-        const int ext = (e == 2) ? (g.zhi - g.zlo + 1) : g.n[e];
+        const unsigned ext = (e == 2) ? (unsigned)(g.zhi - g.zlo + 1) : (unsigned)g.n[e];
         idx[e] = (int)(rem % ext) + (e == 2 ? g.zlo + g.kz0 : 0);
         rem /= ext;
     }
@@ -139,9 +141,10 @@ int op_bc_vec_fused(const G &g, T *a, const double *A, int saveexit, int permask
         for (int e = 0; e < D; ++e) if (e != q) cells *= (e == 2 ? (long)(g.zhi - g.zlo + 1) : (long)g.n[e]);
         total += cells * D;
     }
+    if (total >= (1L << 31)) return fail(WL_E_ARG, "BC!: more than 2^31 ghost cells", __FILE__, __LINE__);
     Prof p(WL_K_BC, total);
     hipLaunchKernelGGL((k_bc_vec_all<T, D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, g, a, (T)A[0],
-                       (T)A[1], (T)(D > 2 ? A[2] : 0.0), saveexit, permask, total);
+                       (T)A[1], (T)(D > 2 ? A[2] : 0.0), saveexit, permask, (unsigned)total);
     return (int)hipGetLastError();
 }
 
@@ -313,6 +316,8 @@ int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T 
                 if (exchange_u) WL_TRY((halo_exchange<T>(g, const_cast<T *>(u), D, 2)));
                 WL_TRY((launch_convdiff3<T, FUSE, COPY>(g, r, u, nu_, u0, u0out, V, dt_, acc, has_acc)));
             }
+            // (the two x-ghost planes -- strided, latency-bound, 0.07 + 0.21 ms at 512^3 -- were also tried on a side stream
+            //  next to the LDS kernel: no gain, 29.73 vs 29.74 ms per step)
             Range R0 = r_whole(g), R1 = r_whole(g);
             R0.hi[0] = 0;
             R1.lo[0] = g.n[0] - 1;
@@ -397,9 +402,18 @@ int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu
     if constexpr (D == 3) {
         // two passes: (1) 16-B vector kernel streams u (+)= f on the body-free rows, (2) the scalar range kernel below
         // evaluates the general statement on the busy rows only (coalesced per cell; ~5 % of the rows for a sphere)
-        if (rowfree && stencil7_ok<T>(g)) {
+        if (rowfree && stencil7_ok<T>(g) && rowvec_fits<T>(g)) {
             using VA = VecA<T>;
             struct Dat { VA f[3], u[3]; int free; };
+            auto busy_rows = [&]() -> int {   // the general statement on the compact list of busy rows (built by wl_flow_update)
+                if (nbusy == 0) return 0;
+                const int ntx = (g.n[0] - 2 + 63) / 64;
+                const long nw = (long)nbusy * ntx;
+                Prof p(WL_K_BDIM, (long)nbusy * (g.n[0] - 2));
+                hipLaunchKernelGGL((k_bdim2_busy<T, MODE>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx().stream, g, u, f, V,
+                                   mu0, mu1, busy, nbusy, ntx);
+                return (int)hipGetLastError();
+            };
             const int rc = launch_rowvec<T, 0, false>(WL_K_BDIM, g,
                 [=] __device__(long o, int j, int k, const Pre &) {
                     Dat d;
@@ -430,15 +444,7 @@ _Pragma("unroll")
             WL_TRY(halo_end());
             if (rc > 0) return rc;
             if (rc == 0) skip_free = true;
-            if (skip_free && busy) {   // compact list of busy interior rows (built by wl_flow_update): touch only those
-                if (nbusy == 0) return 0;
-                const int ntx = (g.n[0] - 2 + 63) / 64;
-                const long nw = (long)nbusy * ntx;
-                Prof p(WL_K_BDIM, (long)nbusy * (g.n[0] - 2));
-                hipLaunchKernelGGL((k_bdim2_busy<T, MODE>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx().stream, g, u, f, V,
-                                   mu0, mu1, busy, nbusy, ntx);
-                return (int)hipGetLastError();
-            }
+            if (skip_free && busy) return busy_rows();
         }
     }
     WL_TRY(halo_end());

@@ -492,6 +492,12 @@ inline void chunking(int tpp, int nown, int cap, int target_k, int *clen, int *n
     *nchunk = (nown + *clen - 1) / *clen;
 }
 
+// will launch_rowvec accept this level?  (one plane's workgroups must fit the partial buffer)
+template <class T> inline bool rowvec_fits(const G &g) {
+    constexpr int V = Vec16<T>::V;
+    const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + 3) / 4;
+    return ((ntx * nty + 7) / 8) * 8 <= WL_MAXB;
+}
 template <class T, int NRED, bool RK, class LD, class ST, int OP = RED_SUM>
 inline int launch_rowvec(int kclass, const G &g, LD ld, ST st, const T *rowc, double *partials, int *np, Gate gate = Gate(),
                          int kov_lo = 0, int kov_hi = -1) {
