@@ -390,7 +390,7 @@ __device__ __forceinline__ void convdiff3s_tile(CdsShared<T> &S_, const G &g, T 
             const int pp = par ^ 1;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                T fxh = __shfl_down(cfx[c], 1, 64);
+                T fxh = lane_dn1(cfx[c]);
                 const double xe = xedge[pp][c][ty];
                 const bool lastc = (i + 1 == ie);
                 if (lastc) fxh = (T)xe;

@@ -594,7 +594,7 @@ template <class T> __device__ __forceinline__ FaceDat<T> face_load(const G &g, c
 // upper x neighbour of element v of the lane's vector: next element, next lane's first element, or the loaded cell
 template <class T> __device__ __forceinline__ void face_xup(const G &g, const FaceDat<T> &d, int i, T (&xu)[VecA<T>::V]) {
     constexpr int V = VecA<T>::V;
-    T nxt = __shfl_down(d.x0.v[0], 1, 64);
+    T nxt = lane_dn1(d.x0.v[0]);
     if ((threadIdx.x & 63) == 63 || i + V > g.n[0] - 2) nxt = d.xr;
 #pragma unroll
     for (int v = 0; v < V; ++v) xu[v] = (v == V - 1) ? nxt : d.x0.v[v == V - 1 ? v : v + 1];
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64 * S7_BY) void k_correct3(G g, T *__restrict__ u,
         const int kn = min(k + 1, k1 - 1);
         nxt = request(kn);
         rcn = rowk_load<T>(rowc, ju + n1 * kn);
-        T left = __shfl_up(cur.xc.v[V - 1], 1, 64);
+        T left = lane_up1(cur.xc.v[V - 1]);
         if (lane == 0) left = cur.left;
         auto plane = [&](auto FAST) {   // two copies: in a coefficient-uniform row nothing can load L (see RowKU)
             constexpr bool F = decltype(FAST)::value;

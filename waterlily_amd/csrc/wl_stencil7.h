@@ -379,11 +379,11 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
                     } else {
                         lx = VA::load(Lx + o); ly0 = VA::load(Ly + o); ly1 = VA::load(Ly + o + sy);
                         lz0 = VA::load(Lz + o); lz1 = VA::load(Lz + o + sz);
-                        lxr = __shfl_down(lx.v[0], 1, 64);
+                        lxr = lane_dn1(lx.v[0]);
                         if (last) lxr = Lx[o + V];
                     }
                     // x neighbours of the vector ends: adjacent lane, or the (prefetched) cell beyond the strip
-                    T left = __shfl_up(ec[q].v[V - 1], 1, 64), right = __shfl_down(ec[q].v[0], 1, 64);
+                    T left = lane_up1(ec[q].v[V - 1]), right = lane_dn1(ec[q].v[0]);
                     if (first) left = src.sxf(cur.lf[q], rc, o - 1, i - 1);
                     if (last) right = src.sxf(cur.rg[q], rc, o + V, i + V);
                     const VA &ym = (q == 0) ? ylo : ec[q == 0 ? 0 : q - 1];
