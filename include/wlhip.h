@@ -252,7 +252,7 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  * key 6: 1 = multigrid levels <= 4096 cells run as one single-workgroup launch per V-cycle (default), 0 = per-op launches
  * key 7: 1 = BC! as one closed-form launch (default), 0 = the reference's sequence of plane loops
  * key 4: rows per thread of the vectorised 7-point kernel (a 256-thread workgroup covers 4x that many rows): 1, 2, or
- *        0 (default) = 2 on levels of >= 2^24 interior cells with an even y extent, else 1.  Same values either way.
+ *        0 (default) = 2 on levels of >= 2^26 interior cells with an even y extent, else 1.  Same values either way.
  * key 8: 1 = pcg! applies x += alpha*eps in the direction kernel instead of the update kernel (default; one array
  *        pass less per iteration, identical values), 0 = in the update kernel as the reference orders it
  * key 9: 1 = the 7-point kernels skip the loads of L in rows whose face coefficients are all one number (rows clear
@@ -267,6 +267,7 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  *         (Flow.jl:144,139) are one pass over x, each rounding kept (default), 0 = two passes
  * key 18: 1 = conv_diff! evaluates each interior face flux once and shares it between the two cells (shared-flux LDS kernel
  *         on the tiles / planes whose y and z faces are all interior) (default), 0 = every cell gathers its six fluxes
+ * key 20: 1 = the shared-flux conv_diff! kernel uses 64x8 tiles (512-thread workgroups) for Float32 (default), 0 = 64x4
  * keys 16, 17: grid size of the 7-point / streaming vector kernels in units of 1024 workgroups (defaults 4 / 16: measured
  *         at 512^3, the streaming kernels gain 3-6 % from shorter z-chunks, the 7-point kernels do not)
  * keys 11, 12: > 0 = cap on the number of z-chunks of the 7-point / streaming vector kernels (measurement only) */

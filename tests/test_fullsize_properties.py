@@ -154,14 +154,14 @@ def test_traffic_saving_switches_do_not_change_a_bit(S, N):
     import bench
     sims = []
     for on in (1, 0):
-        for key in (3, 8, 9, 13, 14, 18):
+        for key in (3, 8, 9, 13, 14, 18, 20):
             S.set_option(key, on)
         try:
             sim = bench.sphere((N, N, N), T)
             for _ in range(3):
                 S.sim_step(sim, remeasure=False)
         finally:
-            for key in (3, 8, 9, 13, 14, 18):
+            for key in (3, 8, 9, 13, 14, 18, 20):
                 S.set_option(key, 1)
         sims.append(sim)
     a, b = sims

@@ -94,14 +94,15 @@ def test_conv_diff_bit_exact(T, Ng, perdir):
 
 
 @pytest.mark.parametrize("T", TYPES)
-@pytest.mark.parametrize("Ng", [(200, 14, 12), (70, 22, 10), (130, 30, 7), (66, 10, 9)])
-@pytest.mark.parametrize("shared", [1, 0])
+@pytest.mark.parametrize("Ng", [(200, 14, 12), (70, 22, 10), (130, 30, 7), (66, 10, 9), (66, 38, 8)])
+@pytest.mark.parametrize("shared", [1, 2, 0])
 def test_conv_diff_tile_paths_bit_exact(T, Ng, shared):
     """The LDS conv_diff kernels on shapes that exercise every tile kind: several x tiles per row (first / last with the
     domain's x-boundary faces, plain ones in between), partially filled last tiles, first / last tile rows and boundary
     planes (the per-cell-gather kernel) around the interior block (the shared-flux kernel, wl_set_option(18)): bit-exact
     against the oracle either way."""
-    S.set_option(18, shared)
+    S.set_option(18, 1 if shared else 0)
+    S.set_option(20, 0 if shared == 2 else 1)            # shared == 2: 64x4 tiles only (the default mixes 64x8 and 64x4)
     try:
         u = rnd(Ng + (3,), T, 8)
         r, Phi = O.zeros(Ng + (3,), T), O.zeros(Ng, T)
@@ -111,6 +112,7 @@ def test_conv_diff_tile_paths_bit_exact(T, Ng, shared):
         same(rd, r)
     finally:
         S.set_option(18, 1)
+        S.set_option(20, 1)
 
 
 @pytest.mark.parametrize("T", TYPES)

@@ -252,14 +252,16 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
 // x-boundary tiles (first / last tile of a row) stay on this path: the one boundary face of such a tile takes the
 // one-sided flux (GENX) and, for the upper boundary, the Float64 accumulation of Flow.jl:55.
 // Same arithmetic per flux, same order of the six updates => bit-identical to k_convdiff3 and to the oracle.
-template <class T> struct CdsShared {
-    T sm[3][3][CD_R][CD_W];            // [plane slot][component][row][col]
-    T fyb[2][3][CD_BY][CD_BX];         // lower-y fluxes of the tile's cells, by plane parity
-    T yedge[2][3][CD_BX];              // y flux through face j0+4
-    double xedge[2][3][CD_BY];         // x flux through face ie (Float64: the upper x boundary accumulates in it)
+// BY = rows of cells per tile = wavefronts per workgroup (4 or 8: an 8-row tile stages 68x12 cells per 64x8 owned instead
+// of 68x8 per 64x4 -- the halo share of the u reads drops from 2.1x to 1.6x)
+template <class T, int BY> struct CdsShared {
+    T sm[3][3][BY + 2 * CD_H][CD_W];   // [plane slot][component][row][col]
+    T fyb[2][3][BY][CD_BX];            // lower-y fluxes of the tile's cells, by plane parity
+    T yedge[2][3][CD_BX];              // y flux through face j0+BY
+    double xedge[2][3][BY];            // x flux through face ie (Float64: the upper x boundary accumulates in it)
 };
-template <class T, bool FUSE, bool COPY, bool GENX>
-__device__ __forceinline__ void convdiff3s_tile(CdsShared<T> &S_, const G &g, T *__restrict__ r, const T *__restrict__ u, T nu, const T *u0,
+template <class T, bool FUSE, bool COPY, bool GENX, int BY>
+__device__ __forceinline__ void convdiff3s_tile(CdsShared<T, BY> &S_, const G &g, T *__restrict__ r, const T *__restrict__ u, T nu, const T *u0,
                                                 T *u0out, const T *__restrict__ V, T dt, double a0, double a1, double a2, bool has_acc,
                                                 int i0, int j0, int ie, int k0, int k1) {
     auto &sm = S_.sm; auto &fyb = S_.fyb; auto &yedge = S_.yedge; auto &xedge = S_.xedge;
@@ -272,16 +274,17 @@ __device__ __forceinline__ void convdiff3s_tile(CdsShared<T> &S_, const G &g, T 
     const long col = (long)ic + g.s[1] * (long)j;  // own column offset (clamped for idle lanes)
     const long sz = g.s[2], sc = g.sc;
 
-    // halo duties of this thread: halo cell h1 = t, and h2 = t + 256 when < 288
+    // halo duties of this thread: halo cell h1 = t, and h2 = t + NT when that is still a halo cell
+    constexpr int NT = CD_BX * BY, NHALO = CD_W * (BY + 2 * CD_H) - CD_BX * BY;
     int hl[2] = {0, 0};
     long hg[2] = {0, 0};
     int nh = 0;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int h = (int)threadIdx.x + q * 256;
-        if (h < CD_HALO) {
+        const int h = (int)threadIdx.x + q * NT;
+        if (h < NHALO) {
             int row, cl;
-            if (h < 4 * CD_W) { const int rr = h / CD_W; row = rr < 2 ? rr : rr + CD_BY; cl = h - rr * CD_W; }
+            if (h < 4 * CD_W) { const int rr = h / CD_W; row = rr < 2 ? rr : rr + BY; cl = h - rr * CD_W; }
             else { const int qq = h - 4 * CD_W; row = CD_H + (qq >> 2); const int c4 = qq & 3; cl = c4 < 2 ? c4 : c4 + CD_BX; }
             const int gx = min(max(i0 - CD_H + cl, 0), n0 - 1), gy = min(max(j0 - CD_H + row, 0), n1 - 1);
             hl[nh] = row * CD_W + cl;
@@ -360,11 +363,11 @@ __device__ __forceinline__ void convdiff3s_tile(CdsShared<T> &S_, const G &g, T 
             fyb[par][c][ty][tx] = fy[c];
         }
         // ---- B'. the tile's outermost upper faces, one extra evaluation per wavefront (all operands from LDS):
-        //      wavefronts 0..2: y face j0+4 of column tx for component ty; wavefront 3 (lanes 0..11): x face ie of row lane/3
+        //      wavefronts 0..2: y face j0+BY of column tx for component ty; wavefront 3 (lanes 0..3BY-1): x face ie of row lane/3
         if (own) {
             if (ty < 3) {
                 const int c = ty;
-                const int el = (CD_BY + CD_H) * CD_W + tx + CD_H;     // LDS offset of cell (i0+tx, j0+4)
+                const int el = (BY + CD_H) * CD_W + tx + CD_H;        // LDS offset of cell (i0+tx, j0+BY)
                 const T *P = SM(s1, c) + el;
                 const T *PY = SM(s1, 1) + el;
                 double vf;
@@ -372,7 +375,7 @@ __device__ __forceinline__ void convdiff3s_tile(CdsShared<T> &S_, const G &g, T 
                 else if (c == 1) vf = (double)((T)(PY[0] + PY[-CD_W]) * (T)0.5);
                 else vf = (double)((T)(PY[0] + SM(s0, 1)[el]) * (T)0.5);
                 yedge[par][c][tx] = (T)cd_flux<T, false>(P[-2 * CD_W], P[-CD_W], P[0], P[CD_W], vf, nu, false, false);
-            } else if (tx < 3 * CD_BY) {
+            } else if (ty == 3 && tx < 3 * BY) {
                 const int rr = tx / 3, c = tx - 3 * rr;
                 const int xl = (rr + CD_H) * CD_W + (ie - i0) + CD_H;   // LDS offset of cell (ie, j0+rr)
                 const T *P = SM(s1, c) + xl;
@@ -394,7 +397,7 @@ __device__ __forceinline__ void convdiff3s_tile(CdsShared<T> &S_, const G &g, T 
                 const double xe = xedge[pp][c][ty];
                 const bool lastc = (i + 1 == ie);
                 if (lastc) fxh = (T)xe;
-                const T fyh = (ty < CD_BY - 1) ? fyb[pp][c][ty + 1][tx] : yedge[pp][c][tx];
+                const T fyh = (ty < BY - 1) ? fyb[pp][c][ty + 1][tx] : yedge[pp][c][tx];
                 T v = (T)0 + cfx[c];
                 v = (GENX && xtop && lastc) ? (T)((double)v - xe) : v - fxh;
                 v = v + cfy[c];
@@ -429,21 +432,21 @@ __device__ __forceinline__ void convdiff3s_tile(CdsShared<T> &S_, const G &g, T 
 }
 // One launch covers every x tile of the interior tile rows; a tile holding a domain x-boundary face (first / last of a
 // row: uniform per workgroup) runs the copy of the plane loop with the one-sided flux variants (GENX), the others the plain one.
-template <class T, bool FUSE, bool COPY>
-__global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3s(G g, T *__restrict__ r, const T *__restrict__ u, T nu, const T *u0, T *u0out,
-                                                            const T *__restrict__ V, T dt, double a0, double a1, double a2, bool has_acc,
-                                                            int ntx, int tpp, int nblk, int clen, int ty0, int klo, int khi, int ntile) {
-    __shared__ CdsShared<T> S_;
+template <class T, bool FUSE, bool COPY, int BY>
+__global__ __launch_bounds__(CD_BX *BY) void k_convdiff3s(G g, T *__restrict__ r, const T *__restrict__ u, T nu, const T *u0, T *u0out,
+                                                         const T *__restrict__ V, T dt, double a0, double a1, double a2, bool has_acc,
+                                                         int ntx, int tpp, int nblk, int clen, int jbase, int klo, int khi, int ntile) {
+    __shared__ CdsShared<T, BY> S_;
     const int b = blockIdx.x;
     const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);  // XCD-contiguous logical id
     const int ch = lb / tpp, pt = lb - ch * tpp;
     const int n0 = g.n[0], n1 = g.n[1];
-    const int i0 = 1 + CD_BX * (pt % ntx), j0 = CD_BY * (ty0 + pt / ntx);
+    const int i0 = 1 + CD_BX * (pt % ntx), j0 = jbase + BY * (pt / ntx);   // jbase: first row of this launch's tile rows
     const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);      // this chunk of planes (all z faces interior)
-    if (k0 > khi || pt >= ntile || j0 + CD_BY - 1 > n1 - 3 || i0 > n0 - 2) return;   // uniform per workgroup (padding tiles)
+    if (k0 > khi || pt >= ntile || j0 + BY - 1 > n1 - 3 || i0 > n0 - 2) return;   // uniform per workgroup (padding tiles)
     const int ie = min(i0 + CD_BX, n0 - 1);       // the x face beyond the tile's last cell
-    if (i0 == 1 || ie == n0 - 1) convdiff3s_tile<T, FUSE, COPY, true>(S_, g, r, u, nu, u0, u0out, V, dt, a0, a1, a2, has_acc, i0, j0, ie, k0, k1);
-    else convdiff3s_tile<T, FUSE, COPY, false>(S_, g, r, u, nu, u0, u0out, V, dt, a0, a1, a2, has_acc, i0, j0, ie, k0, k1);
+    if (i0 == 1 || ie == n0 - 1) convdiff3s_tile<T, FUSE, COPY, true, BY>(S_, g, r, u, nu, u0, u0out, V, dt, a0, a1, a2, has_acc, i0, j0, ie, k0, k1);
+    else convdiff3s_tile<T, FUSE, COPY, false, BY>(S_, g, r, u, nu, u0, u0out, V, dt, a0, a1, a2, has_acc, i0, j0, ie, k0, k1);
 }
 
 // host side.  One tile row = CD_BY rows of cells starting at j0 = CD_BY*ty; the shared-flux kernel takes the tile rows
@@ -492,17 +495,30 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
     // (3) interior planes, interior tile rows: shared-flux kernel; x-boundary tiles in a launch of their own (GENX)
     const int nty = thi - tlo + 1;
     const int nown = khi - klo + 1;
-    const int ntile = ntx * nty;
-    const int tpp = ((ntile + 7) / 8) * 8;
-    int want = WL_GRID / tpp;
-    if (want < 1) want = 1;
-    if (want > nown) want = nown;
-    const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
-    const int nblk = tpp * nchunk;
-    Prof p(WL_K_CONVDIFF, (long)g.n[0] * (long)(nty * CD_BY) * nown);
-    hipLaunchKernelGGL((k_convdiff3s<T, FUSE, COPY>), dim3(nblk), dim3(CD_BX * CD_BY), 0, ctx().stream, g, r, u, (T)nu_, u0, u0out, V,
-                       (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen, tlo, klo, khi, ntile);
-    return (int)hipGetLastError();
+    // 8-row tiles where the element type leaves room for them in LDS (Float32: 43 KB per workgroup), 4-row tiles for the
+    // rows that do not fill one (and for Float64)
+    auto launch = [&](auto BYc, int jbase, int ntr) -> int {   // ntr tile rows of BY rows starting at row jbase
+        constexpr int BY = decltype(BYc)::value;
+        if (ntr <= 0) return 0;
+        const int ntile = ntx * ntr;
+        const int tpp = ((ntile + 7) / 8) * 8;
+        int want = WL_GRID / tpp;
+        if (want < 1) want = 1;
+        if (want > nown) want = nown;
+        const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
+        const int nblk = tpp * nchunk;
+        Prof p(WL_K_CONVDIFF, (long)g.n[0] * (long)(ntr * BY) * nown);
+        hipLaunchKernelGGL((k_convdiff3s<T, FUSE, COPY, BY>), dim3(nblk), dim3(CD_BX * BY), 0, ctx().stream, g, r, u, (T)nu_, u0, u0out, V,
+                           (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen, jbase, klo, khi, ntile);
+        return (int)hipGetLastError();
+    };
+    const int rows = nty * CD_BY, jb0 = tlo * CD_BY;
+    if (sizeof(T) == 4 && ctx().opt[20]) {
+        const int n8 = rows / 8;
+        WL_TRY(launch(std::integral_constant<int, 8>{}, jb0, n8));
+        return launch(std::integral_constant<int, 4>{}, jb0 + 8 * n8, (rows - 8 * n8) / 4);
+    }
+    return launch(std::integral_constant<int, 4>{}, jb0, nty);
 }
 
 }  // namespace wl

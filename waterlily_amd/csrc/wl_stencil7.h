@@ -597,14 +597,14 @@ inline int launch_stencil7_r(int kclass, const G &g, SRC src, const T *L, const 
     return (int)hipGetLastError();
 }
 // rows per thread: wl_set_option(4, .): 1 or 2 forced; 0 (default) = the source's preference (2 for array / Jacobi
-// sources, 1 for the prolongation source) on levels of at least 2^24 interior cells whose y extent is even (half the
+// sources, 1 for the prolongation source) on levels of at least 2^26 interior cells whose y extent is even (half the
 // halo-row traffic; the larger register window costs occupancy, which only the big levels can afford to trade), else 1
 template <class T, int NRED, class SRC, class EPI>
 inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, const T *rowc, const T *ea, const T *eb, EPI epi,
                            double *partials, int *np, Gate gate = Gate(), int kov_lo = 0, int kov_hi = -1) {
     const int want = ctx().opt[4];
     const bool even = ((g.n[1] - 2) % 2) == 0;
-    const bool two = even && (want == 2 || (want == 0 && SRC::ROWS_AUTO == 2 && r_inside(g).count() >= (1L << 24)));
+    const bool two = even && (want == 2 || (want == 0 && SRC::ROWS_AUTO == 2 && r_inside(g).count() >= (1L << 26)));
     if (two) return launch_stencil7_r<T, NRED, 2>(kclass, g, src, L, rowc, ea, eb, epi, partials, np, gate, kov_lo, kov_hi);
     return launch_stencil7_r<T, NRED, 1>(kclass, g, src, L, rowc, ea, eb, epi, partials, np, gate, kov_lo, kov_hi);
 }
