@@ -268,6 +268,10 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  * key 18: 1 = conv_diff! evaluates each interior face flux once and shares it between the two cells (shared-flux LDS kernel
  *         on the tiles / planes whose y and z faces are all interior) (default), 0 = every cell gathers its six fluxes
  * key 20: 1 = the shared-flux conv_diff! kernel uses 64x8 tiles (512-thread workgroups) for Float32 (default), 0 = 64x4
+ * key 22: 1 = inside wl_mom_step / wl_project (3-D, one device) z = div(u) is formed by the residual! kernel itself, the
+ *         z array is neither written nor read (default), 0 = separate div pass
+ * key 21: 1 = the two x-ghost planes of a 3-D conv_diff! are one launch that stages its operands in LDS (default),
+ *         0 = two launches of the per-cell gather
  * keys 16, 17: grid size of the 7-point / streaming vector kernels in units of 1024 workgroups (defaults 4 / 16: measured
  *         at 512^3, the streaming kernels gain 3-6 % from shorter z-chunks, the 7-point kernels do not)
  * keys 11, 12: > 0 = cap on the number of z-chunks of the 7-point / streaming vector kernels (measurement only) */

@@ -103,6 +103,7 @@ def test_conv_diff_tile_paths_bit_exact(T, Ng, shared):
     against the oracle either way."""
     S.set_option(18, 1 if shared else 0)
     S.set_option(20, 0 if shared == 2 else 1)            # shared == 2: 64x4 tiles only (the default mixes 64x8 and 64x4)
+    S.set_option(21, 0 if shared == 0 else 1)            # shared == 0: x-ghost planes by the per-cell gather as well
     try:
         u = rnd(Ng + (3,), T, 8)
         r, Phi = O.zeros(Ng + (3,), T), O.zeros(Ng, T)
@@ -113,6 +114,7 @@ def test_conv_diff_tile_paths_bit_exact(T, Ng, shared):
     finally:
         S.set_option(18, 1)
         S.set_option(20, 1)
+        S.set_option(21, 1)
 
 
 @pytest.mark.parametrize("T", TYPES)
@@ -409,6 +411,32 @@ def test_mom_step_3d_sphere(T):
     check_step(so, sh, T, 3)
     fo, fh = O.pressure_force(so), S.pressure_force(sh)
     assert np.allclose(fo, fh, rtol=1e-4 if T == np.float32 else 1e-9, atol=1e-6 if T == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_project_div_inside_residual_bit_exact(T):
+    """wl_set_option(22): inside mom_step! the right-hand side z = div(u) of project! is formed by the residual! kernel
+    itself (no z array pass).  Same differences in the same order => every field after several steps is bit-identical
+    to the run with the separate div pass, which in turn matches the oracle."""
+    m = 48
+    R, c = m / 8, m / 2 - 1
+    runs = []
+    for fused in (1, 0):
+        S.set_option(22, fused)
+        try:
+            so, sh = pair((m, m, m), (1.0, 0.0, 0.0), 2 * R, nu=2 * R / 3700, body=bodies.sphere(c, R), T=T)
+            for _ in range(3):
+                S.sim_step(sh, remeasure=False)
+            runs.append((sh.pois.n[:], S.to_host(sh.flow.u).copy(), S.to_host(sh.flow.p).copy(), list(sh.flow.dt)))
+        finally:
+            S.set_option(22, 1)
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    assert runs[0][3] == runs[1][3]
+    for _ in range(3):
+        O.sim_step(so, remeasure=False)
+    assert so.pois.n == runs[0][0]
+    assert np.max(np.abs(runs[0][1].astype(np.float64) - so.flow.u)) <= rtol(T) * 50 * float(np.max(np.abs(so.flow.u)))
 
 
 def test_c1_full_size_2d_circle_f64():

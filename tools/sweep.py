@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-launch time of the finest-level kernel classes on the BASELINE sphere for several values of one
-wl_set_option key, in ONE process.  usage: sweep.py <size> <key> <v1> <v2> ... [--f64]"""
+wl_set_option key, in ONE process.  usage: sweep.py <size> <key> <v1> <v2> ... [--f64]
+env: WL_CLASSES=a,b,..  WL_MINFRAC=0.5 (launches of at least this share of the cells; 0 = every launch of the class)
+WL_TOTAL=1 (ms per step summed over the selected launches instead of the per-launch mean)"""
 import ctypes as C
 import os
 import sys
@@ -34,11 +36,11 @@ for rep in range(2):
         row = []
         for nm in classes:
             _lib.check(L.wl_prof_reset())
-            _lib.check(L.wl_prof_select(names[nm], int(0.5 * size ** 3)))
+            _lib.check(L.wl_prof_select(names[nm], int(float(os.environ.get("WL_MINFRAC", "0.5")) * size ** 3)))
             S.sim_step(sim, remeasure=False)
             nl, nc, ms = C.c_int64(), C.c_int64(), C.c_double()
             _lib.check(L.wl_prof_timed(C.byref(nl), C.byref(nc), C.byref(ms)))
-            row.append(ms.value / max(1, nl.value))
+            row.append(ms.value if os.environ.get("WL_TOTAL") else ms.value / max(1, nl.value))   # WL_TOTAL: ms per step of the class
         _lib.check(L.wl_prof_select(-1, 0))
         import time as _t
         import torch as _torch

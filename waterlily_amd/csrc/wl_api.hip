@@ -313,9 +313,10 @@ template <class T, int D> static int mg_vcycle(wl_mg *m, int l, int *pcg_np = nu
 
 // solver!  src/MultiLevelPoisson.jl:87-99 (nlev>1) / src/Poisson.jl:162-172 (nlev==1).
 // One host synchronisation per iteration: the r2 < tol test (:95).
-template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, int *n_iter) {
+// divu / gu: the right-hand side is div(u) of this velocity field, evaluated inside residual! (project!, single device)
+template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, int *n_iter, const T *divu = nullptr, const G *gu = nullptr) {
     LevelT<T> p = lvl<T>(m, 0);
-    WL_TRY((op_residual<T, D>(p, m->permask, m->sc.partials, m->sc.st)));
+    WL_TRY((op_residual<T, D>(p, m->permask, m->sc.partials, m->sc.st, divu, gu)));
     int n = 0;
     while (n < itmx) {
         int pre = -1;
@@ -348,6 +349,7 @@ template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double d
     const double dts = sc.s;
     const bool dbl = sc.dbl;
     const Range R = r_inside(g);
+    bool fused_div = false;
     if (exchange_u && D == 3 && g.dist && overlap_on() && R.hi[2] - R.lo[2] + 1 >= 2) {
         WL_TRY((halo_begin<T>(g, (T *)a->d.u, D, 1)));
         int rc = head_done ? 0 : op_scale_all<T, D>(g, p.x, dts, false, dbl);
@@ -357,10 +359,13 @@ template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double d
         WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u, R.hi[2], R.hi[2])));
     } else {
         if (exchange_u) WL_TRY((halo_exchange<T>(g, (T *)a->d.u, D, 1)));
-        WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u)));
+        // single device, 3-D vector kernels: z = div(u) is formed inside residual! (wl_set_option(22)); p.z stays unwritten
+        fused_div = D == 3 && !g.dist && ctx().opt[22] && ctx().opt[5] && stencil7_ok<T>(g) && stencil7_ok<T>(p.g) && b->permask == 0 &&
+                    g.s[1] == p.g.s[1] && g.s[2] == p.g.s[2] && g.n[0] == p.g.n[0];
+        if (!fused_div) WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u)));
         if (!head_done) WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
     }
-    WL_TRY((mg_solve<T, D>(b, 1e-4, 32, n_iter)));
+    WL_TRY((mg_solve<T, D>(b, 1e-4, 32, n_iter, fused_div ? (const T *)a->d.u : nullptr, &g)));
     WL_TRY((op_correct<T, D>(g, (T *)a->d.u, p.L, p.x, p.rowc)));
     return op_scale_all<T, D>(g, p.x, dts, true, dbl, tail_then);
 }

@@ -41,7 +41,7 @@ struct Comm {
 };
 
 struct Ctx {
-    int opt[24] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 0, 1, 0, 0, 0};   // wl_set_option
+    int opt[24] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 0, 1, 1, 1, 0};   // wl_set_option
     Comm *comm = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -242,6 +242,12 @@ template <class F>
 __global__ __launch_bounds__(WL_BX *WL_BY) void k_range(Tiling t, F f) {
     WL_TILE_LOOP(t, f(idx[0], idx[1], idx[2]);)
 }
+// the same launch, left at once by every workgroup unless *flag (a device flag written by an earlier kernel of the stream)
+template <class F>
+__global__ __launch_bounds__(WL_BX *WL_BY) void k_range_if(Tiling t, const int *flag, F f) {
+    if (!*flag) return;
+    WL_TILE_LOOP(t, f(idx[0], idx[1], idx[2]);)
+}
 
 enum RedOp { RED_SUM = 0, RED_MAX = 1 };
 
@@ -336,6 +342,14 @@ inline int launch_range(int kclass, const Range &R, F f) {
     Tiling t = mk_tiling(R);
     Prof p(kclass, R.count());
     hipLaunchKernelGGL((k_range<F>), dim3(grid_for(t)), dim3(WL_BX * WL_BY), 0, ctx().stream, t, f);
+    return (int)hipGetLastError();
+}
+template <class F>
+inline int launch_range_if(int kclass, const Range &R, const int *flag, F f) {
+    if (R.count() <= 0) return 0;
+    Tiling t = mk_tiling(R);
+    Prof p(kclass, R.count());
+    hipLaunchKernelGGL((k_range_if<F>), dim3(grid_for(t)), dim3(WL_BX * WL_BY), 0, ctx().stream, t, flag, f);
     return (int)hipGetLastError();
 }
 // returns the number of partials per value through *np

@@ -57,20 +57,31 @@ template <class T, bool GEN = true> __device__ __forceinline__ T cd_sub(T r, dou
 
 // COPY (predictor, Flow.jl:154): `a.u0 .= a.u` is folded in -- the kernel reads u, writes u0out = u for every cell it
 // owns and uses that value in the BDIM epilogue (saves the separate 6T copy pass).
+// One launch covers up to CD_NSEG boxes of tiles ("segments": a range of planes x a range of tile rows, each with its own
+// chunking): the shell around the shared-flux kernel's box -- the two boundary plane pairs, the first and the last tile
+// rows -- is four small boxes, which as four launches in a row cost more than the work in them (4 x 33 us at 512^3).
+constexpr int CD_NSEG = 4;
+struct CdSeg { int b0, nblk, tpp, clen, ty0, ntile, zlo, zhi; };   // b0: first block of the segment (multiple of 8)
+struct CdSegs { int n; CdSeg s[CD_NSEG]; };
 template <class T, bool FUSE, bool COPY>
 __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__ r, const T *__restrict__ u, T nu,
                                                            const T *u0, T *u0out, const T *__restrict__ V, T dt,
                                                            double a0, double a1, double a2, bool has_acc, int ntx,
-                                                           int tpp, int nblk, int clen, int ty0, int ntile) {
+                                                           CdSegs segs) {
     __shared__ T sm[3][3][CD_R][CD_W];  // [plane slot][component][row][col]
     const int tx = threadIdx.x & (CD_BX - 1), ty = threadIdx.x / CD_BX;
-    const int b = blockIdx.x;
+    CdSeg sg = segs.s[0];
+#pragma unroll
+    for (int q = 1; q < CD_NSEG; ++q)
+        if (q < segs.n && (int)blockIdx.x >= segs.s[q].b0) sg = segs.s[q];   // (scalar selects: uniform per workgroup)
+    const int nblk = sg.nblk, tpp = sg.tpp, clen = sg.clen, ty0 = sg.ty0, ntile = sg.ntile, zlo = sg.zlo, zhi = sg.zhi;
+    const int b = (int)blockIdx.x - sg.b0;
     const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);  // XCD-contiguous logical id
     const int ch = lb / tpp, pt = lb - ch * tpp;
-    const int i0 = 1 + CD_BX * (pt % ntx), j0 = CD_BY * (ty0 + pt / ntx);   // ty0: first tile row of this launch
+    const int i0 = 1 + CD_BX * (pt % ntx), j0 = CD_BY * (ty0 + pt / ntx);   // ty0: first tile row of this segment
     const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2], nzg = g.nzg, kz0 = g.kz0;
-    const int k0 = g.zlo + ch * clen, k1 = min(g.zhi + 1, k0 + clen);   // this chunk of the OWNED planes
-    if (k0 > g.zhi || j0 >= n1 || pt >= ntile) return;  // uniform per workgroup (padding tiles)
+    const int k0 = zlo + ch * clen, k1 = min(zhi + 1, k0 + clen);   // this chunk of the segment's (owned) planes
+    if (k0 > zhi || j0 >= n1 || pt >= ntile) return;  // uniform per workgroup (padding tiles)
     const int i = i0 + tx, j = j0 + ty;
     const bool active = (i <= n0 - 2) && (j <= n1 - 1);
     const int ic = min(i, n0 - 1), jc = min(j, n1 - 1);
@@ -453,22 +464,35 @@ __global__ __launch_bounds__(CD_BX *BY) void k_convdiff3s(G g, T *__restrict__ r
 // whose cells have interior y faces only (2 <= j0, j0+CD_BY-1 <= n1-3) on the planes whose cells have interior z faces
 // only (global plane 2 .. nzg-3; every plane on a periodic ring of slabs); k_convdiff3 takes the first / last tile row
 // and the boundary planes; the two x-ghost planes go through the generic gather kernel (caller).
+struct CdBox { int zlo, zhi, ty0, nty; };   // planes [zlo, zhi] x tile rows [ty0, ty0+nty)
 template <class T, bool FUSE, bool COPY>
-int launch_convdiff3_old(const G &g, int ty0, int nty, T *r, const T *u, double nu_, const T *u0, T *u0out, const T *V, double dt_,
-                         const double (&a3)[3], bool has_acc) {
-    if (nty <= 0 || g.zhi < g.zlo) return 0;
+int launch_convdiff3_old(const G &g, const CdBox *box, int nbox, T *r, const T *u, double nu_, const T *u0, T *u0out, const T *V,
+                         double dt_, const double (&a3)[3], bool has_acc) {
     const int ntx = (g.n[0] - 2 + CD_BX - 1) / CD_BX;
-    const int tpp = ((ntx * nty + 7) / 8) * 8;  // padded to a multiple of 8 for the XCD mapping (idle tail tiles)
-    const int nown = g.zhi - g.zlo + 1;
-    int want = WL_GRID / tpp;
-    if (want < 1) want = 1;
-    if (want > nown) want = nown;
-    const int clen = (nown + want - 1) / want;
-    const int nchunk = (nown + clen - 1) / clen;
-    const int nblk = tpp * nchunk;
-    Prof p(WL_K_CONVDIFF, (long)g.n[0] * (long)(nty * CD_BY) * nown);
+    CdSegs segs;
+    segs.n = 0;
+    int nblk = 0;
+    long cells = 0;
+    for (int q = 0; q < nbox && segs.n < CD_NSEG; ++q) {
+        const CdBox &bx = box[q];
+        if (bx.nty <= 0 || bx.zhi < bx.zlo) continue;
+        const int tpp = ((ntx * bx.nty + 7) / 8) * 8;  // padded to a multiple of 8 for the XCD mapping (idle tail tiles)
+        const int nown = bx.zhi - bx.zlo + 1;
+        int want = WL_GRID / tpp;
+        if (want < 1) want = 1;
+        if (want > nown) want = nown;
+        int clen = (nown + want - 1) / want;
+        if (clen < 8) clen = nown < 8 ? nown : 8;   // a chunk re-reads ~4 planes ahead of its first one: keep chunks >= 8 planes
+        const int nchunk = (nown + clen - 1) / clen;
+        segs.s[segs.n++] = CdSeg{nblk, tpp * nchunk, tpp, clen, bx.ty0, ntx * bx.nty, bx.zlo, bx.zhi};
+        nblk += tpp * nchunk;
+        cells += (long)g.n[0] * (long)(bx.nty * CD_BY) * nown;
+    }
+    if (!segs.n) return 0;
+    for (int q = segs.n; q < CD_NSEG; ++q) segs.s[q] = segs.s[0];
+    Prof p(WL_K_CONVDIFF, cells);
     hipLaunchKernelGGL((k_convdiff3<T, FUSE, COPY>), dim3(nblk), dim3(CD_BX * CD_BY), 0, ctx().stream, g, r, u, (T)nu_, u0,
-                       u0out, V, (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen, ty0, ntx * nty);
+                       u0out, V, (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, segs);
     return (int)hipGetLastError();
 }
 template <class T, bool FUSE, bool COPY>
@@ -478,20 +502,25 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
     if (has_acc) for (int d = 0; d < 3; ++d) a3[d] = acc[d];
     const int ntx = (g.n[0] - 2 + CD_BX - 1) / CD_BX, nty_all = (g.n[1] + CD_BY - 1) / CD_BY;
     // tile rows with interior y faces only: ty in [tlo, thi]
-    const int tlo = 1, thi = (g.n[1] - 3 - (CD_BY - 1)) / CD_BY;      // CD_BY*ty + CD_BY-1 <= n1-3
+    const int tlo = 1;
+    int thi = (g.n[1] - 3 - (CD_BY - 1)) / CD_BY;      // CD_BY*ty + CD_BY-1 <= n1-3
     // planes with interior z faces only, clipped to the owned planes
     int klo = g.zlo, khi = g.zhi;
     if (!g.zring) { klo = max(klo, 2 - g.kz0); khi = min(khi, g.nzg - 3 - g.kz0); }
-    const bool shared = ctx().opt[18] != 0 && thi >= tlo && khi >= klo;
-    if (!shared) return launch_convdiff3_old<T, FUSE, COPY>(g, 0, nty_all, r, u, nu_, u0, u0out, V, dt_, a3, has_acc);
-    // (1) boundary planes: every tile row, old kernel
-    if (klo > g.zlo) { G gb = g; gb.zhi = klo - 1; WL_TRY((launch_convdiff3_old<T, FUSE, COPY>(gb, 0, nty_all, r, u, nu_, u0, u0out, V, dt_, a3, has_acc))); }
-    if (khi < g.zhi) { G gb = g; gb.zlo = khi + 1; WL_TRY((launch_convdiff3_old<T, FUSE, COPY>(gb, 0, nty_all, r, u, nu_, u0, u0out, V, dt_, a3, has_acc))); }
-    // (2) interior planes, first / last tile rows: old kernel
-    G gi = g;
-    gi.zlo = klo; gi.zhi = khi;
-    WL_TRY((launch_convdiff3_old<T, FUSE, COPY>(gi, 0, tlo, r, u, nu_, u0, u0out, V, dt_, a3, has_acc)));
-    WL_TRY((launch_convdiff3_old<T, FUSE, COPY>(gi, thi + 1, nty_all - (thi + 1), r, u, nu_, u0, u0out, V, dt_, a3, has_acc)));
+    const bool use8 = sizeof(T) == 4 && ctx().opt[20] != 0;
+    int thi_s = thi;
+    if (use8 && ((thi_s - tlo + 1) & 1) && thi_s > tlo) --thi_s;   // 8-row tiles: an odd tile row goes to the shell
+    const bool shared = ctx().opt[18] != 0 && thi_s >= tlo && khi >= klo;
+    if (!shared) {
+        const CdBox all{g.zlo, g.zhi, 0, nty_all};
+        return launch_convdiff3_old<T, FUSE, COPY>(g, &all, 1, r, u, nu_, u0, u0out, V, dt_, a3, has_acc);
+    }
+    thi = thi_s;
+    // (1)+(2) the shell, ONE launch of the per-cell kernel: boundary planes (every tile row), and on the interior planes
+    // the first / last tile rows
+    const CdBox shell[4] = {{g.zlo, klo - 1, 0, nty_all}, {khi + 1, g.zhi, 0, nty_all},
+                            {klo, khi, 0, tlo}, {klo, khi, thi + 1, nty_all - (thi + 1)}};
+    WL_TRY((launch_convdiff3_old<T, FUSE, COPY>(g, shell, 4, r, u, nu_, u0, u0out, V, dt_, a3, has_acc)));
     // (3) interior planes, interior tile rows: shared-flux kernel; x-boundary tiles in a launch of their own (GENX)
     const int nty = thi - tlo + 1;
     const int nown = khi - klo + 1;
@@ -513,7 +542,7 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
         return (int)hipGetLastError();
     };
     const int rows = nty * CD_BY, jb0 = tlo * CD_BY;
-    if (sizeof(T) == 4 && ctx().opt[20]) {
+    if (use8) {
         const int n8 = rows / 8;
         WL_TRY(launch(std::integral_constant<int, 8>{}, jb0, n8));
         return launch(std::integral_constant<int, 4>{}, jb0 + 8 * n8, (rows - 8 * n8) / 4);

@@ -99,17 +99,18 @@ __global__ __launch_bounds__(256) void k_bc_vec_all(G g, T *a, T A0, T A1, T A2,
     }
     while (d < D - 1 && rem >= per[d]) { rem -= per[d]; ++d; }
     if (rem >= per[d]) return;
-    const int c = (int)(rem % D);
-    rem /= D;
-    const int pl = (int)(rem % 3);
-    rem /= 3;
+    // position in the plane fastest (for the y and z planes consecutive lanes then write consecutive x: one 256-B
+    // segment per wavefront instead of nine 28-B pieces), then the plane, then the component
     int idx[3] = {0, 0, 0};   // GLOBAL indices
     for (int e = 0; e < D; ++e) {
-        if (e == d) { idx[e] = pl == 0 ? 0 : (pl == 1 ? 1 : ng[e] - 1); continue; }
+        if (e == d) continue;
         const unsigned ext = (e == 2) ? (unsigned)(g.zhi - g.zlo + 1) : (unsigned)g.n[e];
         idx[e] = (int)(rem % ext) + (e == 2 ? g.zlo + g.kz0 : 0);
         rem /= ext;
     }
+    const int pl = (int)(rem % 3);
+    const int c = (int)(rem / 3);
+    idx[d] = pl == 0 ? 0 : (pl == 1 ? 1 : ng[d] - 1);
     if (D > 2 && d == 2) {   // z planes: only the rank that owns them (nobody on a periodic ring: halo exchange fills them)
         const int kl = idx[2] - g.kz0;
         if (g.zring || kl < g.zlo || kl > g.zhi) return;
@@ -213,6 +214,62 @@ int op_reduce(const G &g, int kclass, int op, double init, F cell, double *parti
 // each interior flux rounded to T first exactly like the Phi scratch does (:45-47); boundary faces are added
 // in Float64 like :54-55.  No Phi array, no 9x re-read of r, no write race.
 // FUSE: also applies accelerate! (:68-70) and the first BDIM! loop (:133): f = u0 + dt*r - V on ALL cells.
+// flux sum of component c at one cell, every operand addressed as ub[jd*csz + I +- k*st[jd]]: the velocity array itself
+// (csz = g.sc, st = g.s) or an LDS patch of it with its own strides (k_convdiff_xghost below)
+template <class T, int D>
+__device__ __forceinline__ T cd_gather_rr(const T *ub, long csz, const long (&st)[3], long I, const int (&idx)[3], const int (&N)[3],
+                                          bool zring, int permask, T nu, int c) {
+    const T *ui = ub + (long)c * csz;
+    const long si = st[c];
+    T rr = 0;
+_Pragma("unroll")
+    for (int jd = 0; jd < D; ++jd) {
+        const int Nj = N[jd];
+        const bool ring = (jd == 2) && zring;   // periodic ring of slabs: every z face is an interior face
+        if (!ring && idx[jd] > Nj - 2) continue;
+        const T *uj = ub + (long)jd * csz;
+        const long sj = st[jd];
+        const bool per = ((permask >> jd) & 1) && !ring;
+        {   // lower face of the cell: face index I
+            const double uf = phi<T>(uj, I, si);
+            const T nud = nu * (T)(ui[I] - ui[I - sj]);
+            if (!ring && idx[jd] == 1) {
+                if (!per) {
+                    rr = (T)((double)rr + (phiuL<T>(ui, I, sj, uf) - (double)nud));
+                } else {
+                    const T P = (T)(phiuP<T>(ui, I + (long)(Nj - 4) * sj, I, sj, uf) - (double)nud);
+                    rr += P;
+                }
+            } else {
+                const T P = (T)(phiu<T>(ui, I, sj, uf) - (double)nud);
+                rr += P;
+            }
+        }
+        {   // upper face of the cell: face index I+sj
+            const long J = I + sj;
+            if (!ring && idx[jd] == Nj - 2) {
+                if (!per) {
+                    const double uf = phi<T>(uj, J, si);
+                    const T nud = nu * (T)(ui[J] - ui[J - sj]);
+                    rr = (T)((double)rr + (-phiuR<T>(ui, J, sj, uf) + (double)nud));
+                } else {  // :60  r[I-d] -= Phi[CIj(j,I,2)] : the lower-boundary flux, wrapped
+                    const long I2 = I - (long)(idx[jd] - 1) * sj;
+                    const double uf = phi<T>(uj, I2, si);
+                    const T nud = nu * (T)(ui[I2] - ui[I2 - sj]);
+                    const T P = (T)(phiuP<T>(ui, I2 + (long)(Nj - 4) * sj, I2, sj, uf) - (double)nud);
+                    rr -= P;
+                }
+            } else {
+                const double uf = phi<T>(uj, J, si);
+                const T nud = nu * (T)(ui[J] - ui[J - sj]);
+                const T P = (T)(phiu<T>(ui, J, sj, uf) - (double)nud);
+                rr -= P;
+            }
+        }
+    }
+    return rr;
+}
+
 template <class T, int D, bool FUSE, bool COPY = false>
 int op_conv_diff_range(const G &g, const Range &R, T *r, const T *u, double nu_, int permask, const T *u0, const T *V,
                        double dt_, const double *acc, bool has_acc, T *u0out = nullptr) {
@@ -224,64 +281,18 @@ int op_conv_diff_range(const G &g, const Range &R, T *r, const T *u, double nu_,
     return launch_range(WL_K_CONVDIFF, R, [=] __device__(int i, int j, int k) {
         const long I = gg.at(i, j, k);
         const int idx[3] = {i, j, gg.kg(k)};   // z index in global numbering
+        const int N[3] = {gg.n[0], gg.n[1], gg.nzg};
+        const long st[3] = {gg.s[0], gg.s[1], gg.s[2]};
         bool lowok = true;
 _Pragma("unroll")
         for (int d = 0; d < D; ++d) lowok = lowok && (idx[d] >= 1 || (d == 2 && gg.zring));
 _Pragma("unroll")
         for (int c = 0; c < D; ++c) {
-            const T *ui = u + (long)c * gg.sc;
-            const long si = gg.s[c];
             T rr = 0;
-            if (lowok) {
-_Pragma("unroll")
-                for (int jd = 0; jd < D; ++jd) {
-                    const int Nj = (jd == 2) ? gg.nzg : gg.n[jd];
-                    const bool ring = (jd == 2) && gg.zring;   // periodic ring of slabs: every z face is an interior face
-                    if (!ring && idx[jd] > Nj - 2) continue;
-                    const T *uj = u + (long)jd * gg.sc;
-                    const long sj = gg.s[jd];
-                    const bool per = ((permask >> jd) & 1) && !ring;
-                    {   // lower face of the cell: face index I
-                        const double uf = phi<T>(uj, I, si);
-                        const T nud = nu * (T)(ui[I] - ui[I - sj]);
-                        if (!ring && idx[jd] == 1) {
-                            if (!per) {
-                                rr = (T)((double)rr + (phiuL<T>(ui, I, sj, uf) - (double)nud));
-                            } else {
-                                const T P = (T)(phiuP<T>(ui, I + (long)(Nj - 4) * sj, I, sj, uf) - (double)nud);
-                                rr += P;
-                            }
-                        } else {
-                            const T P = (T)(phiu<T>(ui, I, sj, uf) - (double)nud);
-                            rr += P;
-                        }
-                    }
-                    {   // upper face of the cell: face index I+sj
-                        const long J = I + sj;
-                        if (!ring && idx[jd] == Nj - 2) {
-                            if (!per) {
-                                const double uf = phi<T>(uj, J, si);
-                                const T nud = nu * (T)(ui[J] - ui[J - sj]);
-                                rr = (T)((double)rr + (-phiuR<T>(ui, J, sj, uf) + (double)nud));
-                            } else {  // :60  r[I-d] -= Phi[CIj(j,I,2)] : the lower-boundary flux, wrapped
-                                const long I2 = I - (long)(idx[jd] - 1) * sj;
-                                const double uf = phi<T>(uj, I2, si);
-                                const T nud = nu * (T)(ui[I2] - ui[I2 - sj]);
-                                const T P = (T)(phiuP<T>(ui, I2 + (long)(Nj - 4) * sj, I2, sj, uf) - (double)nud);
-                                rr -= P;
-                            }
-                        } else {
-                            const double uf = phi<T>(uj, J, si);
-                            const T nud = nu * (T)(ui[J] - ui[J - sj]);
-                            const T P = (T)(phiu<T>(ui, J, sj, uf) - (double)nud);
-                            rr -= P;
-                        }
-                    }
-                }
-            }
+            if (lowok) rr = cd_gather_rr<T, D>(u, gg.sc, st, I, idx, N, gg.zring, permask, nu, c);
             if (FUSE) {
                 if (has_acc) rr = (T)((double)rr + (c == 0 ? a0 : (c == 1 ? a1 : a2)));
-                const T uo = COPY ? ui[I] : u0[I + (long)c * gg.sc];
+                const T uo = COPY ? u[I + (long)c * gg.sc] : u0[I + (long)c * gg.sc];
                 if (COPY) u0out[I + (long)c * gg.sc] = uo;
                 r[I + (long)c * gg.sc] = (uo + dt * rr) - V[I + (long)c * gg.sc];
             } else {
@@ -289,6 +300,75 @@ _Pragma("unroll")
             }
         }
     });
+}
+
+// The two x-ghost planes of a 3-D, non-periodic conv_diff! (i = 0: no flux at all; i = n0-1: y and z fluxes only,
+// util.jl:55-57 "top ghost included") in ONE launch.  As a plain gather a thread of these planes issues ~100 loads, each
+// lane on its own cache line (the plane is strided by the row pitch): 0.07 + 0.21 ms at 512^3 for 0.4 % of the cells.
+// Here a 64(y) x 4(z) tile first stages what its cells read -- the three components in columns n0-2, n0-1 over the tile
+// + 2 halo rows / planes -- in LDS (13 loads per thread, all in flight together) and evaluates the same expressions
+// (cd_gather_rr) on the patch.
+constexpr int XG_BJ = 64, XG_BK = 4, XG_H = 2;
+constexpr int XG_ROWS = XG_BJ + 2 * XG_H, XG_PL = XG_BK + 2 * XG_H;
+constexpr int XG_SY = 2, XG_SZ = XG_SY * XG_ROWS, XG_CS = XG_SZ * XG_PL;   // patch strides: x, y, z, component
+template <class T, bool FUSE, bool COPY>
+__global__ __launch_bounds__(XG_BJ *XG_BK) void k_convdiff_xghost(G g, T *__restrict__ r, const T *__restrict__ u, T nu, const T *u0,
+                                                                  T *u0out, const T *__restrict__ V, T dt, double a0, double a1,
+                                                                  double a2, bool has_acc, int ntj, int ntile, int klo, int khi) {
+    __shared__ T pt[3 * XG_CS];
+    const int role_top = (int)blockIdx.x < ntile;              // the heavier plane first
+    const int tb = role_top ? (int)blockIdx.x : (int)blockIdx.x - ntile;
+    const int j0 = XG_BJ * (tb % ntj), k0 = klo + XG_BK * (tb / ntj);
+    const int tj = threadIdx.x & (XG_BJ - 1), tk = threadIdx.x / XG_BJ;
+    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
+    const int j = j0 + tj, k = k0 + tk;
+    const bool active = (j <= n1 - 1) && (k <= khi);
+    const int i = role_top ? n0 - 1 : 0;
+    if (role_top) {
+        for (int e = threadIdx.x; e < 3 * XG_CS; e += XG_BJ * XG_BK) {
+            const int c = e / XG_CS, e1 = e - c * XG_CS;
+            const int p = e1 / XG_SZ, e2 = e1 - p * XG_SZ;
+            const int row = e2 >> 1, x = e2 & 1;
+            const int gj = min(max(j0 - XG_H + row, 0), n1 - 1), gk = min(max(k0 - XG_H + p, 0), n2 - 1);
+            pt[e] = u[(long)c * g.sc + (long)(n0 - 2 + x) + g.s[1] * (long)gj + g.s[2] * (long)gk];
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    const long I = g.at(i, j, k);
+    const int idx[3] = {i, j, g.kg(k)};
+    const int N[3] = {n0, n1, g.nzg};
+    const long st[3] = {1, XG_SY, XG_SZ};
+    const long Il = 1 + XG_SY * (long)(tj + XG_H) + XG_SZ * (long)(tk + XG_H);
+    const bool lowok = role_top && idx[1] >= 1 && (idx[2] >= 1 || g.zring);
+_Pragma("unroll")
+    for (int c = 0; c < 3; ++c) {
+        T rr = 0;
+        if (lowok) rr = cd_gather_rr<T, 3>(pt, XG_CS, st, Il, idx, N, g.zring, 0, nu, c);
+        const long q = I + (long)c * g.sc;
+        if (FUSE) {
+            if (has_acc) rr = (T)((double)rr + (c == 0 ? a0 : (c == 1 ? a1 : a2)));
+            const T uo = COPY ? u[q] : u0[q];
+            if (COPY) u0out[q] = uo;
+            r[q] = (uo + dt * rr) - V[q];
+        } else {
+            r[q] = rr;
+        }
+    }
+}
+template <class T, bool FUSE, bool COPY>
+int launch_convdiff_xghost(const G &g, T *r, const T *u, double nu_, const T *u0, const T *V, double dt_, const double *acc,
+                           bool has_acc, T *u0out) {
+    const Range R = r_whole(g);
+    const int nk = R.hi[2] - R.lo[2] + 1;
+    if (nk <= 0) return 0;
+    double a3[3] = {0, 0, 0};
+    if (has_acc) for (int d = 0; d < 3; ++d) a3[d] = acc[d];
+    const int ntj = (g.n[1] + XG_BJ - 1) / XG_BJ, ntile = ntj * ((nk + XG_BK - 1) / XG_BK);
+    Prof p(WL_K_CONVDIFF, 2L * g.n[1] * nk);
+    hipLaunchKernelGGL((k_convdiff_xghost<T, FUSE, COPY>), dim3(2 * ntile), dim3(XG_BJ * XG_BK), 0, ctx().stream, g, r, u, (T)nu_, u0,
+                       u0out, V, (T)dt_, a3[0], a3[1], a3[2], has_acc, ntj, ntile, R.lo[2], R.hi[2]);
+    return (int)hipGetLastError();
 }
 
 // dispatch: D=3 non-periodic -> LDS-tiled marching kernel (wl_convdiff.h) + generic gather on the two x-ghost
@@ -318,6 +398,7 @@ int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T 
             }
             // (the two x-ghost planes -- strided, latency-bound, 0.07 + 0.21 ms at 512^3 -- were also tried on a side stream
             //  next to the LDS kernel: no gain, 29.73 vs 29.74 ms per step)
+            if (ctx().opt[21]) return launch_convdiff_xghost<T, FUSE, COPY>(g, r, u, nu_, u0, V, dt_, acc, has_acc, u0out);
             Range R0 = r_whole(g), R1 = r_whole(g);
             R0.hi[0] = 0;
             R1.lo[0] = g.n[0] - 1;
@@ -835,8 +916,38 @@ int op_mult(const LevelT<T> &p, T *x, int permask) {
 }
 
 // residual!  src/Poisson.jl:91-97
+// epilogue of the residual kernel with the right-hand side evaluated on the fly: z[I] = div(I,u) (Flow.jl:139, project!)
+// is not read from p.z but formed from the six face values -- same differences, same order as op_div -- so the pass
+// that writes z and the read of z both disappear (512^3: div 0.42 ms + residual 0.43 ms -> one kernel).  p.z is left
+// unwritten: nothing reads it before pcg! overwrites it (it is pcg!'s scratch for A*eps).
+template <class T> struct ResidualDivEpi {
+    static constexpr bool HAS_LD = true;
+    using VA = VecA<T>;
+    using Dat = FaceDat<T>;
+    G gu; const T *u; const T *iD; T *r; int n0;
+    __device__ __forceinline__ Dat ld(long o, int j, int k) const { return face_load<T>(gu, u, o, j, k); }
+    template <class RKT>
+    __device__ __forceinline__ void operator()(long o, int i, int, int, const VA &ax, const VA &, const Dat &d, const RKT &rk, double *acc,
+                                               const Pre &) const {
+        const VA id = row_iD<T>(rk, iD, o, i, n0);
+        T xu[VA::V];
+        face_xup<T>(gu, d, i, xu);
+        VA rv;
+_Pragma("unroll")
+        for (int v = 0; v < VA::V; ++v) {
+            T s = 0;
+            s += xu[v] - d.x0.v[v];
+            s += d.y1.v[v] - d.y0.v[v];
+            s += d.z1.v[v] - d.z0.v[v];
+            rv.v[v] = (id.v[v] == 0) ? (T)0 : s - ax.v[v];
+            acc[0] += (double)rv.v[v];
+        }
+        rv.store(r + o);
+    }
+};
+// divu / gu (optional, single device): take z = div(u) from the velocity field u laid out like the level (see above)
 template <class T, int D>
-int op_residual(const LevelT<T> &p, int permask, double *partials, State *st) {
+int op_residual(const LevelT<T> &p, int permask, double *partials, State *st, const T *divu = nullptr, const G *gu = nullptr) {
     WL_TRY((op_bc_per<T, D>(p.g, p.x, permask, false)));
     const LevelT<T> q = p;
     int np = 0;
@@ -846,6 +957,13 @@ int op_residual(const LevelT<T> &p, int permask, double *partials, State *st) {
         if (stencil7_ok<T>(p.g)) {
             using VA = VecA<T>;
             exchanged = true;
+            if (divu) {
+                if (p.g.dist || gu->s[1] != p.g.s[1] || gu->s[2] != p.g.s[2] || gu->n[0] != p.g.n[0])
+                    return fail(WL_E_ARG, "residual with div(u): layouts differ", __FILE__, __LINE__);
+                rcv = launch_stencil7<T, 1>(WL_K_RESIDUAL, p.g, SrcArray<T>{p.x}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
+                                            ResidualDivEpi<T>{*gu, divu, q.iD, q.r, q.g.n[0]}, partials, &np);
+                if (rcv != 0) return rcv > 0 ? rcv : fail(WL_E_STATE, "residual with div(u): launch rejected", __FILE__, __LINE__);
+            } else {
             rcv = launch_stencil7_halo<T, 1>(WL_K_RESIDUAL, p.g, p.x, SrcArray<T>{p.x}, p.L, p.rowc, (const T *)nullptr, p.z,
                 [=] __device__(long o, int i, int, int, const VA &ax, const VA &, const VA &, const VA &zz, const auto &rk, double *acc, const Pre &) {
                 const VA id = row_iD<T>(rk, q.iD, o, i, q.g.n[0]);
@@ -858,8 +976,10 @@ _Pragma("unroll")
                 rv.store(q.r + o);
             }, partials, &np);
             if (rcv > 0) return rcv;
+            }
         }
     }
+    if (divu && rcv != 0) return fail(WL_E_STATE, "residual with div(u): needs the 3-D vector kernels", __FILE__, __LINE__);
     if (!exchanged) WL_TRY((halo_exchange<T>(p.g, p.x, 1, 1)));
     if (rcv != 0)
     WL_TRY((launch_range_red<1>(WL_K_RESIDUAL, r_inside(p.g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
@@ -875,8 +995,8 @@ _Pragma("unroll")
         st->shift = (double)s;
         st->do_shift = !((s < 0 ? -s : s) <= eps2);
     })));
-    return launch_range(WL_K_RESIDUAL, r_inside(p.g), [=] __device__(int i, int j, int k) {
-        if (!st->do_shift) return;
+    // (the shift pass is left at once by every workgroup unless the finalize above asked for it)
+    return launch_range_if(WL_K_RESIDUAL, r_inside(p.g), &st->do_shift, [=] __device__(int i, int j, int k) {
         const long I = q.g.at(i, j, k);
         q.r[I] = q.r[I] - (T)st->shift;
     });
@@ -1090,7 +1210,7 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
         int o11, o12; bool on;
         CapGuard(bool on_, int cap) : o11(ctx().opt[11]), o12(ctx().opt[12]), on(on_) { if (on) { ctx().opt[11] = cap; ctx().opt[12] = cap; } }
         ~CapGuard() { if (on) { ctx().opt[11] = o11; ctx().opt[12] = o12; } }
-    } capguard(infin && !distr, (infin && !distr) ? (1024 / tpp_v > 0 ? 1024 / tpp_v : 1) : 0);
+    } capguard(infin && !distr, (infin && !distr) ? std::max(1024 / std::max(tpp_v, 1), 1) : 0);
     // what the consuming gate sums: the producer's partials, or (z-slabs) the one all-reduced value
     auto ready = [&](const double *&part, int &n) -> int {
         if (!distr) return 0;

@@ -262,6 +262,12 @@ template <class T> struct SrcProlong {        // e[I] = coarse x[down(I)] inside
     template <class RKT> __device__ __forceinline__ T sxf(T a, const RKT &, long, int) const { return a; }
 };
 
+// An epilogue may bring its own operand loader (a functor with HAS_LD, `Dat ld(o, j, k)` and
+// `operator()(o, i, j, k, Ae, e, dat, rk, acc, pre)`): ld is called where ea / eb are requested, its result reaches the
+// epilogue at the end of the iteration (op_residual with the divergence evaluated on the fly).  Lambdas have none.
+template <class E, class = void> struct EpiLd { static constexpr bool ON = false; struct Dat {}; };
+template <class E> struct EpiLd<E, std::enable_if_t<E::HAS_LD>> { static constexpr bool ON = true; using Dat = typename E::Dat; };
+
 // One launch of the 7-point kernel.  R rows per thread.  ea / eb: optional epilogue operand arrays, loaded next to the
 // stencil operands (requested at the top of the iteration, consumed by the epilogue at its end).
 // epi(o, i, j, k, Ae, e, a, b, rk, acc, pre): rk = row constants of the cell's own row in plane k.
@@ -344,11 +350,13 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
             const int kn = min(k + 1, kmax);
             // ---- (1) requests: epilogue operands of this plane first (consumed last), then the set of the NEXT iteration
             VA av[R], bv[R];
+            typename EpiLd<EPI>::Dat ex[R];
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 if (SRC::EA_IS_RAW) av[q] = rawc[q];
                 else if (ea) av[q] = VA::load(ea + ok + q * sy);
                 if (eb) bv[q] = VA::load(eb + ok + q * sy);
+                if constexpr (EpiLd<EPI>::ON) ex[q] = epi.ld(ok + q * sy, jb + q, k);
             }
             request(nxt, kn);
             // ---- (2)+(3) in two copies: every row involved in this plane is coefficient-uniform (no L / iD load can occur),
@@ -404,7 +412,8 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
                         s += em[q].v[v] * lz0.v[v] + ep[q].v[v] * lz1.v[v];
                         ae.v[v] = s;
                     }
-                    epi(o, i, jb + q, k, ae, ec[q], (ea || SRC::EA_IS_RAW) ? av[q] : ec[q], eb ? bv[q] : ec[q], rc, acc, pre);
+                    if constexpr (EpiLd<EPI>::ON) epi(o, i, jb + q, k, ae, ec[q], ex[q], rc, acc, pre);
+                    else epi(o, i, jb + q, k, ae, ec[q], (ea || SRC::EA_IS_RAW) ? av[q] : ec[q], eb ? bv[q] : ec[q], rc, acc, pre);
                 }
 #pragma unroll
                 for (int q = 0; q < R; ++q) { em[q] = ec[q]; ec[q] = ep[q]; }
