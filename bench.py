@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 # the GPU box gives one GPU a 16-core CPU share (os.cpu_count() reports the whole host): bound OpenMP to it
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver (before HIP starts)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s float4 copy)
 

@@ -270,6 +270,9 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  * key 20: 1 = the shared-flux conv_diff! kernel uses 64x8 tiles (512-thread workgroups) for Float32 (default), 0 = 64x4
  * key 22: 1 = inside wl_mom_step / wl_project (3-D, one device) z = div(u) is formed by the residual! kernel itself, the
  *         z array is neither written nor read (default), 0 = separate div pass
+ * key 23: 1 = inside wl_mom_step (3-D, x not periodic) the x-ghost cells of the interior rows that BC!(u,U) sets are
+ *         written by the kernel that has just produced the row (BDIM!, the velocity correction); the BC launch that
+ *         follows covers the y and z planes only (default), 0 = BC! writes all six planes
  * key 21: 1 = the two x-ghost planes of a 3-D conv_diff! are one launch that stages its operands in LDS (default),
  *         0 = two launches of the per-cell gather
  * keys 16, 17: grid size of the 7-point / streaming vector kernels in units of 1024 workgroups (defaults 4 / 16: measured

@@ -439,6 +439,33 @@ def test_project_div_inside_residual_bit_exact(T):
     assert np.max(np.abs(runs[0][1].astype(np.float64) - so.flow.u)) <= rtol(T) * 50 * float(np.max(np.abs(so.flow.u)))
 
 
+@pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("exitBC", [False, True])
+def test_x_ghost_cells_written_by_the_producer_bit_exact(T, exitBC):
+    """wl_set_option(23): inside mom_step! the x-ghost cells of the interior rows that BC!(u,U) sets are written by the
+    kernel that produces the row (BDIM!, the velocity correction), the BC launch covers the y / z planes only.  Every
+    element of u -- ghost cells included -- after several steps is bit-identical to the run whose BC! writes all six
+    planes, and matches the oracle."""
+    dims = (264, 24, 16)           # several x tiles per row (256 / 128 cells per wavefront for Float32 / Float64)
+    R, c = dims[1] / 8, dims[1] / 2 - 1
+    runs = []
+    for fold in (1, 0):
+        S.set_option(23, fold)
+        try:
+            so, sh = pair(dims, (1.0, 0.0, 0.0), 2 * R, nu=2 * R / 1000, body=bodies.sphere(c, R), T=T, exitBC=exitBC)
+            for _ in range(3):
+                S.sim_step(sh, remeasure=False)
+            runs.append((sh.pois.n[:], S.to_host(sh.flow.u).copy(), S.to_host(sh.flow.p).copy(), list(sh.flow.dt)))
+        finally:
+            S.set_option(23, 1)
+    assert runs[0][0] == runs[1][0] and runs[0][3] == runs[1][3]
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    for _ in range(3):
+        O.sim_step(so, remeasure=False)
+    assert so.pois.n == runs[0][0]
+    assert np.max(np.abs(runs[0][1].astype(np.float64) - so.flow.u)) <= rtol(T) * 50 * float(np.max(np.abs(so.flow.u)))
+
+
 def test_c1_full_size_2d_circle_f64():
     """BASELINE configs[0] (C1) at its real size: 2-D circle, 192x64, Re=100, Float64 -- 12 steps against the oracle:
     identical V-cycle counts and time steps, u to 1e-10, p to 1e-9, pressure force to 1e-8 (the solver stops at an

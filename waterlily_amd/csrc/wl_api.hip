@@ -342,7 +342,8 @@ template <class T> static ScaleOp project_scale(double dt_, double w) {
     return ScaleOp{dbl ? w * (double)(T)dt_ : (double)(T)dt_, false, dbl};
 }
 template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double dt_, double w, int *n_iter, bool exchange_u = false,
-                                                  bool head_done = false, const ScaleOp *tail_then = nullptr) {
+                                                  bool head_done = false, const ScaleOp *tail_then = nullptr, const XBc<T> *xbc = nullptr,
+                                                  bool *xdone = nullptr) {
     const G g = mkG(&a->d.g);
     LevelT<T> p = lvl<T>(b, 0);
     const ScaleOp sc = project_scale<T>(dt_, w);
@@ -366,7 +367,7 @@ template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double d
         if (!head_done) WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
     }
     WL_TRY((mg_solve<T, D>(b, 1e-4, 32, n_iter, fused_div ? (const T *)a->d.u : nullptr, &g)));
-    WL_TRY((op_correct<T, D>(g, (T *)a->d.u, p.L, p.x, p.rowc)));
+    WL_TRY((op_correct<T, D>(g, (T *)a->d.u, p.L, p.x, p.rowc, xbc, xdone)));
     return op_scale_all<T, D>(g, p.x, dts, true, dbl, tail_then);
 }
 
@@ -382,21 +383,24 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     // predictor (:157-161): a.u0 .= a.u (:154) + conv_diff! + accelerate! + BDIM! #1 in ONE kernel (it reads u, writes
     // u0 and f); scale_u!(a,0) is folded into the predictor BDIM #2 (MODE 1).
     // (z-slab runs: u carries a 2-plane halo for QUICK, f a 1-plane halo for mu_ddn; exchanges are no-ops otherwise)
+    // (the x-ghost cells of the interior rows are written by the kernel that produces the row: XBc, wl_set_option(23))
+    const XBc<T> xbc{(D == 3 && d.perdir_mask == 0 && ctx().opt[7] && ctx().opt[23]) ? 1 : 0, d.exitBC ? 1 : 0, (T)U[0]};
+    bool xd = false;
     WL_TRY((op_conv_diff<T, D, true, true>(g, f, u, d.nu, d.perdir_mask, nullptr, V, dt, gp, gp != nullptr, u0)));
-    WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true)));   // + exchange of f (overlapped)
-    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
+    WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd)));   // + exchange of f (overlapped)
+    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
     if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, u, u0, U, dt, a->sc.partials, a->sc.st)));
     // (the predictor's closing `x ./= dt` and the corrector's opening `x .*= 0.5dt` are ONE pass over x: nothing in between reads p)
     const ScaleOp corr_head = project_scale<T>(dt, 0.5);
     const bool chain = ctx().opt[14] != 0;
-    WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0], true, false, chain ? &corr_head : nullptr)));   // + 1-plane exchange of u (overlapped with div)
-    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
+    WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0], true, false, chain ? &corr_head : nullptr, &xbc, &xd)));   // + 1-plane exchange of u (overlapped with div)
+    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
     // corrector (:164-167); the 2-plane exchange of u is issued inside op_conv_diff (overlapped with its inner planes)
     WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr, nullptr, true)));
-    WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true)));
-    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
-    WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true, chain)));
-    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask)));
+    WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd)));
+    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
+    WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true, chain, nullptr, &xbc, &xd)));
+    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
     // push!(a.dt, CFL(a)) (:168); the end-of-step 2-plane exchange of u is issued inside (overlapped with the kernel)
     WL_TRY((op_cfl<T, D>(g, (T *)d.sigma, u, d.nu, a->sc.partials, a->sc.st, true)));
     WL_TRY(a->sc.fetch());

@@ -38,10 +38,26 @@ inline long span(const G &g) { return g.D == 3 ? (long)g.n[2] * g.s[2] : (long)g
 // ------------------------------------------------------------------------------------------ util.jl
 // BC!(a,A,saveexit,perdir)  src/util.jl:192-210 -- same sequence of plane loops as the reference, because
 // later planes read ghost values written by earlier ones (edges/corners).
-template <class T, int D> int op_bc_vec_fused(const G &g, T *a, const double *A, int saveexit, int permask);
+template <class T, int D> int op_bc_vec_fused(const G &g, T *a, const double *A, int saveexit, int permask, bool skip_x = false);
+// The x part of BC!(u,U) on the INTERIOR rows is row-local when x is not periodic (normal component: u[0] = u[1] = U0,
+// u[n-1] = U0 unless the exit is saved; tangential components: u[0] = u[1], u[n-1] = u[n-2]), so the kernel that has just
+// produced a row of u (BDIM!, the velocity correction) writes those cells itself, into DRAM pages it is streaming anyway.
+// As a launch of its own the three x planes -- one cache line per cell -- cost 0.1 ms at 512^3, the y and z planes
+// 0.02 ms; every x-plane cell of a ghost ROW is covered by the y / z planes of the BC kernel (skip_x).
+template <class T> struct XBc { int on, saveexit; T U0; };
+template <class T> __device__ __forceinline__ void xbc_apply(const XBc<T> &b, T *u, long o, long sc, int i, int n0, VecA<T> (&uv)[3]) {
+    constexpr int V = VecA<T>::V;
+    if (!b.on) return;
+    if (i == 1) { uv[0].v[0] = b.U0; u[o - 1] = b.U0; u[o - 1 + sc] = uv[1].v[0]; u[o - 1 + 2 * sc] = uv[2].v[0]; }
+    if (i + V - 1 == n0 - 2) {
+        if (!b.saveexit) u[o + V] = b.U0;
+        u[o + V + sc] = uv[1].v[V - 1]; u[o + V + 2 * sc] = uv[2].v[V - 1];
+    }
+}
 template <class T, int D>
-int op_bc_vec(const G &g, T *a, const double *A, int saveexit, int permask) {
-    if (ctx().opt[7]) return op_bc_vec_fused<T, D>(g, a, A, saveexit, permask);   // one launch (closed form), see below
+int op_bc_vec(const G &g, T *a, const double *A, int saveexit, int permask, bool skip_x = false) {
+    if (ctx().opt[7]) return op_bc_vec_fused<T, D>(g, a, A, saveexit, permask, skip_x);   // one launch (closed form), see below
+    if (skip_x) return fail(WL_E_STATE, "BC!: x planes folded into the producer need the one-launch form", __FILE__, __LINE__);
     for (int c = 0; c < D; ++c)
         for (int j = 0; j < D; ++j) {
             T *ac = a + (long)c * g.sc;
@@ -82,34 +98,22 @@ int op_bc_vec(const G &g, T *a, const double *A, int saveexit, int permask) {
 // continue at the clamped source index, normal j -> the Dirichlet value A[i] (planes 1,2,N; N skipped when saving the
 // exit).  The walk ends on a cell no pass writes, so every thread reads only never-written cells: no ordering hazard.
 template <class T, int D>
-__global__ __launch_bounds__(256) void k_bc_vec_all(G g, T *a, T A0, T A1, T A2, int saveexit, int permask, unsigned nthreads) {
-    // (32-bit index arithmetic: the ghost-cell count of any grid that fits this part is far below 2^31; a 64-bit
-    //  division costs ~4x a 32-bit one and this decode has eight of them)
-    const unsigned t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= nthreads) return;
-    // thread -> (direction d, plane p in {0,1,n-1}, position in the plane, component c)
+__global__ __launch_bounds__(256) void k_bc_vec_all(G g, T *a, T A0, T A1, T A2, int saveexit, int permask, int combo0) {
+    // blockIdx.y -> (direction d, plane pl in {0,1,n-1}, component c): uniform per workgroup, decoded on the scalar unit;
+    // blockIdx.x*256 + thread -> position in the plane, first remaining axis fastest (for the y and z planes consecutive
+    // lanes write consecutive x).  One 32-bit division per thread (the flat decode of round 1 had eight: VALU-bound).
     const int ng[3] = {g.n[0], g.n[1], D > 2 ? g.nzg : 1};
-    unsigned rem = t;
-    int d = 0;
-    unsigned per[3];
-    for (int q = 0; q < D; ++q) {
-        unsigned cells = 3;
-        for (int e = 0; e < D; ++e) if (e != q) cells *= (e == 2 ? (unsigned)(g.zhi - g.zlo + 1) : (unsigned)g.n[e]);
-        per[q] = cells * D;
-    }
-    while (d < D - 1 && rem >= per[d]) { rem -= per[d]; ++d; }
-    if (rem >= per[d]) return;
-    // position in the plane fastest (for the y and z planes consecutive lanes then write consecutive x: one 256-B
-    // segment per wavefront instead of nine 28-B pieces), then the plane, then the component
+    const int combo = (int)blockIdx.y + combo0;   // combo0 = 3*D: the x planes are not part of this launch
+    const int c = combo % D, pl = (combo / D) % 3, d = combo / (3 * D);
+    const int e1 = d == 0 ? 1 : 0, e2 = (D > 2) ? (d == 2 ? 1 : 2) : -1;
+    const unsigned ext1 = (e1 == 2) ? (unsigned)(g.zhi - g.zlo + 1) : (unsigned)g.n[e1];
+    const unsigned ext2 = (e2 < 0) ? 1u : ((e2 == 2) ? (unsigned)(g.zhi - g.zlo + 1) : (unsigned)g.n[e2]);
+    const unsigned pos = blockIdx.x * 256u + threadIdx.x;
+    if (pos >= ext1 * ext2) return;
+    const unsigned q2 = pos / ext1, q1 = pos - q2 * ext1;
     int idx[3] = {0, 0, 0};   // GLOBAL indices
-    for (int e = 0; e < D; ++e) {
-        if (e == d) continue;
-        const unsigned ext = (e == 2) ? (unsigned)(g.zhi - g.zlo + 1) : (unsigned)g.n[e];
-        idx[e] = (int)(rem % ext) + (e == 2 ? g.zlo + g.kz0 : 0);
-        rem /= ext;
-    }
-    const int pl = (int)(rem % 3);
-    const int c = (int)(rem / 3);
+    idx[e1] = (int)q1 + (e1 == 2 ? g.zlo + g.kz0 : 0);
+    if (e2 >= 0) idx[e2] = (int)q2 + (e2 == 2 ? g.zlo + g.kz0 : 0);
     idx[d] = pl == 0 ? 0 : (pl == 1 ? 1 : ng[d] - 1);
     if (D > 2 && d == 2) {   // z planes: only the rank that owns them (nobody on a periodic ring: halo exchange fills them)
         const int kl = idx[2] - g.kz0;
@@ -133,19 +137,22 @@ __global__ __launch_bounds__(256) void k_bc_vec_all(G g, T *a, T A0, T A1, T A2,
     a[dst] = dirichlet ? Ac : a[g.at(idx[0], idx[1], D > 2 ? idx[2] - g.kz0 : 0) + (long)c * g.sc];
 }
 template <class T, int D>
-int op_bc_vec_fused(const G &g, T *a, const double *A, int saveexit, int permask) {
+int op_bc_vec_fused(const G &g, T *a, const double *A, int saveexit, int permask, bool skip_x) {
     if (D > 2 && ((permask >> 2) & 1) && g.dist && !g.zring)
         return fail(WL_E_ARG, "periodic z on a z-slab decomposition needs grid.zring", __FILE__, __LINE__);
-    long total = 0;
-    for (int q = 0; q < D; ++q) {
-        long cells = 3;
+    long total = 0, big = 0;
+    for (int q = skip_x ? 1 : 0; q < D; ++q) {
+        long cells = 1;
         for (int e = 0; e < D; ++e) if (e != q) cells *= (e == 2 ? (long)(g.zhi - g.zlo + 1) : (long)g.n[e]);
-        total += cells * D;
+        total += cells * 3 * D;
+        big = cells > big ? cells : big;
     }
-    if (total >= (1L << 31)) return fail(WL_E_ARG, "BC!: more than 2^31 ghost cells", __FILE__, __LINE__);
+    if (big <= 0) return 0;
+    if (big >= (1L << 31)) return fail(WL_E_ARG, "BC!: more than 2^31 cells in a boundary plane", __FILE__, __LINE__);
     Prof p(WL_K_BC, total);
-    hipLaunchKernelGGL((k_bc_vec_all<T, D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream, g, a, (T)A[0],
-                       (T)A[1], (T)(D > 2 ? A[2] : 0.0), saveexit, permask, (unsigned)total);
+    const int combo0 = skip_x ? 3 * D : 0;
+    hipLaunchKernelGGL((k_bc_vec_all<T, D>), dim3((unsigned)((big + 255) / 256), (unsigned)(3 * D * D - combo0)), dim3(256), 0, ctx().stream,
+                       g, a, (T)A[0], (T)A[1], (T)(D > 2 ? A[2] : 0.0), saveexit, permask, combo0);
     return (int)hipGetLastError();
 }
 
@@ -445,7 +452,7 @@ _Pragma("unroll")
 // general BDIM! statement on a compact list of rows (row = j + n1*k), one wavefront per 64-cell row segment
 template <class T, int MODE>
 __global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *f, const T *V, const T *mu0, const T *mu1,
-                                                    const int *rows, int nrows, int ntx) {
+                                                    const int *rows, int nrows, int ntx, XBc<T> xb) {
     const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= (long)nrows * ntx) return;
     const int row = rows[w / ntx];
@@ -464,8 +471,14 @@ __global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *f, const
         }
         const long q = I + (long)c * g.sc;
         const double tmp = (0.5 * (double)s + (double)V[q]) + (double)(T)(mu0[q] * fc[I]);
-        if (MODE == 1) u[q] = (T)(0.0 + tmp);
-        else { const T un = (T)((double)u[q] + tmp); u[q] = (MODE == 2) ? (T)((double)un * 0.5) : un; }
+        T val;
+        if (MODE == 1) val = (T)(0.0 + tmp);
+        else { const T un = (T)((double)u[q] + tmp); val = (MODE == 2) ? (T)((double)un * 0.5) : un; }
+        if (xb.on) {   // the row's x-ghost cells (see XBc)
+            if (i == 1) { if (c == 0) val = xb.U0; u[q - 1] = val; }
+            if (i == g.n[0] - 2 && !(c == 0 && xb.saveexit)) u[q + 1] = (c == 0) ? xb.U0 : val;
+        }
+        u[q] = val;
     }
 }
 
@@ -475,9 +488,12 @@ __global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *f, const
 // over the body-free rows (which reads no neighbour of f) runs while it is in flight, the busy rows after it.
 template <class T, int D, int MODE>
 int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu1, const unsigned char *rowfree = nullptr,
-             const int *busy = nullptr, int nbusy = 0, bool exchange_f = false) {
+             const int *busy = nullptr, int nbusy = 0, bool exchange_f = false, const XBc<T> *xbc = nullptr, bool *xdone = nullptr) {
     const G gg = g;
     if (!ctx().opt[3]) rowfree = nullptr;
+    if (xdone) *xdone = false;
+    XBc<T> xb{0, 0, (T)0};
+    if (xbc && xbc->on && rowfree && busy) xb = *xbc;   // both kernels below take part, or neither
     if (exchange_f) WL_TRY((halo_begin<T>(g, const_cast<T *>(f), D, 1)));   // (in-stream when overlap is off)
     bool skip_free = false;   // the free rows were already done by the vector pass
     if constexpr (D == 3) {
@@ -492,7 +508,7 @@ int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu
                 const long nw = (long)nbusy * ntx;
                 Prof p(WL_K_BDIM, (long)nbusy * (g.n[0] - 2));
                 hipLaunchKernelGGL((k_bdim2_busy<T, MODE>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx().stream, g, u, f, V,
-                                   mu0, mu1, busy, nbusy, ntx);
+                                   mu0, mu1, busy, nbusy, ntx, xb);
                 return (int)hipGetLastError();
             };
             const int rc = launch_rowvec<T, 0, false>(WL_K_BDIM, g,
@@ -508,24 +524,31 @@ _Pragma("unroll")
                     }
                     return d;
                 },
-                [=] __device__(long o, int, int, int, const Dat &d, const auto &, double *, const Pre &) {
+                [=] __device__(long o, int i, int, int, const Dat &d, const auto &, double *, const Pre &) {
                     if (!d.free) return;
+                    VA uv[3];
 _Pragma("unroll")
                     for (int c = 0; c < 3; ++c) {
-                        VA uv = d.u[c];
+                        uv[c] = d.u[c];
 _Pragma("unroll")
                         for (int v = 0; v < VA::V; ++v) {
                             const double tmp = (0.5 * 0.0 + 0.0) + (double)d.f[c].v[v];
-                            if (MODE == 1) uv.v[v] = (T)(0.0 + tmp);
-                            else { const T un = (T)((double)uv.v[v] + tmp); uv.v[v] = (MODE == 2) ? (T)((double)un * 0.5) : un; }
+                            if (MODE == 1) uv[c].v[v] = (T)(0.0 + tmp);
+                            else { const T un = (T)((double)uv[c].v[v] + tmp); uv[c].v[v] = (MODE == 2) ? (T)((double)un * 0.5) : un; }
                         }
-                        uv.store(u + o + (long)c * gg.sc);
                     }
+                    xbc_apply<T>(xb, u, o, gg.sc, i, gg.n[0], uv);
+_Pragma("unroll")
+                    for (int c = 0; c < 3; ++c) uv[c].store(u + o + (long)c * gg.sc);
                 }, (const T *)nullptr, nullptr, nullptr);
             WL_TRY(halo_end());
             if (rc > 0) return rc;
             if (rc == 0) skip_free = true;
-            if (skip_free && busy) return busy_rows();
+            if (skip_free && busy) {
+                if (xdone) *xdone = xb.on != 0;
+                return busy_rows();
+            }
+            if (xb.on) return fail(WL_E_STATE, "BDIM!: x-ghost fold without the vector pass", __FILE__, __LINE__);
         }
     }
     WL_TRY(halo_end());
@@ -720,7 +743,8 @@ _Pragma("unroll")
 // rowc (optional): row constants of L (wl_stencil7.h): in a coefficient-uniform row L is not loaded.
 template <class T>
 __global__ __launch_bounds__(64 * S7_BY) void k_correct3(G g, T *__restrict__ u, const T *__restrict__ L, const T *__restrict__ x,
-                                                  const T *__restrict__ rowc, int ntx, int tpp, int nblk, int clen, int klo, int khi) {
+                                                  const T *__restrict__ rowc, int ntx, int tpp, int nblk, int clen, int klo, int khi,
+                                                  XBc<T> xb) {
     constexpr int V = Vec16<T>::V;
     using VA = VecA<T>;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -763,15 +787,16 @@ __global__ __launch_bounds__(64 * S7_BY) void k_correct3(G g, T *__restrict__ u,
             } else {
                 l0 = VA::load(L + o); l1 = VA::load(L + o + sc); l2 = VA::load(L + o + 2 * sc);
             }
-            VA u0 = cur.u0, u1 = cur.u1, u2 = cur.u2;
+            VA uv[3] = {cur.u0, cur.u1, cur.u2};
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 const T xl = (v == 0) ? left : cur.xc.v[v == 0 ? 0 : v - 1];
-                u0.v[v] -= l0.v[v] * (cur.xc.v[v] - xl);
-                u1.v[v] -= l1.v[v] * (cur.xc.v[v] - cur.xy.v[v]);
-                u2.v[v] -= l2.v[v] * (cur.xc.v[v] - xm.v[v]);
+                uv[0].v[v] -= l0.v[v] * (cur.xc.v[v] - xl);
+                uv[1].v[v] -= l1.v[v] * (cur.xc.v[v] - cur.xy.v[v]);
+                uv[2].v[v] -= l2.v[v] * (cur.xc.v[v] - xm.v[v]);
             }
-            u0.store(u + o); u1.store(u + o + sc); u2.store(u + o + 2 * sc);
+            xbc_apply<T>(xb, u, o, sc, i, g.n[0], uv);   // the row's x-ghost cells of the BC! that follows (see XBc)
+            uv[0].store(u + o); uv[1].store(u + o + sc); uv[2].store(u + o + 2 * sc);
         };
         if (rc.uni()) plane(std::true_type{}); else plane(std::false_type{});
         xm = cur.xc;
@@ -786,7 +811,8 @@ __global__ __launch_bounds__(64 * S7_BY) void k_correct3(G g, T *__restrict__ u,
 
 // u[I,i] -= L[I,i]*d_i x  src/Flow.jl:141-143 (three loops fused: they touch disjoint components)
 template <class T, int D>
-int op_correct(const G &g, T *u, const T *L, const T *x, const T *rowc = nullptr) {
+int op_correct(const G &g, T *u, const T *L, const T *x, const T *rowc = nullptr, const XBc<T> *xbc = nullptr, bool *xdone = nullptr) {
+    if (xdone) *xdone = false;
     if constexpr (D == 3) {
         if (stencil7_ok<T>(g)) {
             constexpr int V = Vec16<T>::V;
@@ -800,8 +826,10 @@ int op_correct(const G &g, T *u, const T *L, const T *x, const T *rowc = nullptr
             if (want > nown) want = nown;
             const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
             Prof p(WL_K_CORRECT, R.count());
+            const XBc<T> xb = (xbc && xbc->on) ? *xbc : XBc<T>{0, 0, (T)0};
             hipLaunchKernelGGL((k_correct3<T>), dim3(tpp * nchunk), dim3(64 * S7_BY), 0, ctx().stream, g, u, L, x, rowc, ntx, tpp,
-                               tpp * nchunk, clen, R.lo[2], R.hi[2]);
+                               tpp * nchunk, clen, R.lo[2], R.hi[2], xb);
+            if (xdone) *xdone = xb.on != 0;
             return (int)hipGetLastError();
         }
     }
