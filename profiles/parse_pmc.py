@@ -50,6 +50,8 @@ def classify(name):
         o = re.search(r"#(\d)\}", name)
         return ROWVEC.get((m.group(1), "#" + o.group(1))) if m and o else None
     if "k_stencil7" in name:
+        if "ResidualDivEpi" in name:
+            return "residual"
         m = re.search(r"(op_\w+?)<", name)
         return S7.get(m.group(1)) if m else None
     m = re.search(r"(k_range_red|k_range)<.*?(op_\w+?)<", name)

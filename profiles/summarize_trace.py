@@ -14,6 +14,9 @@ import sys
 def short(n):
     if "k_convdiff3" in n:
         return "conv_diff(lds)"
+    if "ResidualDivEpi" in n:   # residual! with z = div(u) formed on the fly (functor epilogue, not a lambda of op_residual)
+        rr = re.search(r"k_stencil7<\w+, \d, (\d)", n)
+        return f"op_residual+div[stencil7{',R=' + rr.group(1) if rr else ''}]"
     m = re.search(r"(k_stencil7|k_rowvec|k_range_red|k_range|k_finalize|k_reduce_only|k_apply)<.*?(op_\w+?|red_\w+?)<", n)
     if m:
         lam = re.search(r"#(\d)\}", n)

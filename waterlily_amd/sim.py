@@ -17,6 +17,7 @@ no CPU fallback and construction raises if no GPU is present.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Optional, Sequence
 
 import numpy as np
@@ -83,16 +84,46 @@ class Layout:
     def alloc(self, ncomp: Sequence[int], device, fill: float = 0.0) -> torch.Tensor:
         """A zero (or `fill`) field with trailing component dims `ncomp` ((), (D,), (D,D))."""
         nc = int(np.prod(ncomp)) if len(ncomp) else 1
-        buf = torch.full((self.lead + nc * self.sc + self.align,), fill, dtype=_TORCH[self.T], device=device)
+        buf = _arena_take(self.lead + nc * self.sc + self.align, _TORCH[self.T], device, fill)
         size = self.Ng + tuple(ncomp)
         stride = tuple(self.s[: self.D])
         cs = self.sc
         for _ in ncomp:
             stride += (cs,)
             cs *= ncomp[0]
-        a = torch.as_strided(buf, size, stride, self.lead)
+        a = torch.as_strided(buf, size, stride, buf.storage_offset() + self.lead)
         a._wl_slab = self.slab
         return a
+
+
+# Placement experiment (tools/placement.py, DESIGN.md section 5): fields carved out of ONE device buffer at a chosen
+# spacing instead of one torch allocation per field.  Off unless set_arena() was called.
+_ARENA = {"buf": None, "pos": 0, "round": 1, "skew": 0}
+
+
+def set_arena(nbytes: int, device, round_to: int = 1 << 21, skew: int = 0) -> None:
+    """Carve every field allocated from now on out of one `nbytes` buffer: field k starts at the next multiple of
+    `round_to` after field k-1, plus `skew` bytes.  nbytes = 0 switches back to one torch allocation per field."""
+    if nbytes == 0:
+        _ARENA.update(buf=None, pos=0)
+        return
+    if _ARENA["buf"] is None or _ARENA["buf"].numel() < nbytes:
+        _ARENA["buf"] = None
+        _ARENA["buf"] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    _ARENA.update(pos=0, round=round_to, skew=skew)
+
+
+def _arena_take(nelem: int, dtype, device, fill: float) -> torch.Tensor:
+    a = _ARENA
+    item = torch.empty((), dtype=dtype).element_size()
+    if a["buf"] is None or a["pos"] + nelem * item + a["round"] + a["skew"] > a["buf"].numel():
+        return torch.full((nelem,), fill, dtype=dtype, device=device)
+    start = -(-a["pos"] // a["round"]) * a["round"] + (a["skew"] if a["pos"] else 0)
+    start = -(-start // 256) * 256
+    a["pos"] = start + nelem * item
+    out = a["buf"][start:start + nelem * item].view(dtype)
+    out.fill_(fill)
+    return out
 
 
 def _grid_of(a: torch.Tensor, D: int) -> Grid:
