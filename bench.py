@@ -58,7 +58,7 @@ ALG_T = {
     "smooth":         (9.0,    4.0,    4.0),   # Jacobi!+increment!: r,x -> r,x ; iD, L(3) in non-uniform rows
     "prolongate":     (9.125,  5.125,  4.0),   # prolongate!+increment! (+ start of pcg!): r,x,(coarse x) -> r,x,eps
     "increment":      (9.0,    5.0,    3.0),
-    "residual":       (8.0,    3.0,    4.0),   # x,z -> r
+    "residual":       (12.0,   5.0,    4.0),   # project!: z=div(u) formed inside residual! (div 4T + residual! 8T as written): u(3),x -> r
     "correct":        (10.0,   7.0,    3.0),   # u(3) rw, x ; L(3) in non-uniform rows
     "div":            (4.0,    4.0,    0.0),
     "cfl":            (4.0,    4.0,    0.0),
