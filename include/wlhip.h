@@ -184,6 +184,11 @@ int wl_flow_destroy(wl_flow *a);
  * mu0 == 1 on a whole x-row) that let BDIM! skip those 15 coefficient reads where they are known constants; results
  * are identical with or without the flags.  Until the first call every row takes the general path. */
 int wl_flow_update(wl_flow *a);
+/* update!(pois) after a native measure! (wl_measure_fill) of the flow whose mu0 is this hierarchy's L: on level 0 only the
+ * x-rows that measure! rewrote (and their lower y / z neighbours, whose diagonal reads them) get D, iD and row constants
+ * recomputed -- every other row holds the same values already; levels >= 1 are rebuilt in full.  Same results as
+ * wl_mg_update (to which it falls back when the flow's last change was not a native measure!, or in 2-D). */
+int wl_mg_update_changed(wl_mg *m, const wl_flow *a);
 /* measure!(flow, body; t, eps)        src/Body.jl:31-53 for a PARAMETRIC body: an sdf family with closed-form gradient
  * (what ForwardDiff.gradient returns, src/AutoBody.jl:119) composed with an affine map xi = A x + b evaluated by the
  * host at the measured time together with its time derivative and inverse (AutoBody.jl:128-130: V = -J \ d(map)/dt).

@@ -742,6 +742,30 @@ def test_native_measure_matches_oracle(T):
     assert torch.equal(runs[0].flow.u, runs[1].flow.u) and torch.equal(runs[0].flow.p, runs[1].flow.p)
 
 
+@pytest.mark.parametrize("T", TYPES)
+def test_update_of_changed_rows_equals_full_update(T):
+    """update!(pois) after a native measure! revisits, on the finest level, only the rows that measure! rewrote (plus the
+    lower neighbours whose diagonal reads them): D, iD, the solver's behaviour and every field of a moving-body run are
+    bit-identical to the same run with the full update!."""
+    m = 40
+    mk = lambda: S.Simulation((m, m, m), (1.0, 0.0, 0.0), 8.0, body=bodies.moving_circle(14.0, 5.0, v=1.5, a=0.5, D=3).native(3),
+                              nu=0.05, T=T)
+    a, b = mk(), mk()
+    for _ in range(4):
+        S.sim_step(a)                                   # measure! + update!(pois, flow): changed rows only
+        S.measure_flow(b.flow, b.body, t=float(np.sum(np.asarray(b.flow.dt, dtype=np.float64))), eps=b.eps, geometry=b.geometry)
+        b._band = None
+        S.update(b.pois)                                # full update!
+        S.mom_step(b.flow, b.pois)
+        for k in ("D", "iD"):
+            assert torch.equal(getattr(a.pois.levels[0], k), getattr(b.pois.levels[0], k)), k
+        assert S.uniform_rows(a.pois, 0) == S.uniform_rows(b.pois, 0)
+    assert a.pois.n == b.pois.n
+    assert torch.equal(a.flow.u, b.flow.u) and torch.equal(a.flow.p, b.flow.p)
+    for l in range(1, len(a.pois.levels)):
+        assert torch.equal(a.pois.levels[l].L, b.pois.levels[l].L) and torch.equal(a.pois.levels[l].iD, b.pois.levels[l].iD), l
+
+
 def _inside_mask(shape):
     m = np.zeros(shape, bool)
     m[tuple(slice(1, n - 1) for n in shape)] = True

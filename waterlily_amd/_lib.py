@@ -118,6 +118,7 @@ def lib() -> C.CDLL:
         "wl_mg_create": (i, [C.POINTER(vp), i, i, C.POINTER(LevelDesc), i]),
         "wl_mg_destroy": (i, [vp]),
         "wl_mg_update": (i, [vp]),
+        "wl_mg_update_changed": (i, [vp, vp]),
         "wl_mg_uniform_rows": (i, [vp, i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
         "wl_mg_mult": (i, [vp, i, vp]),
         "wl_mg_residual": (i, [vp, i]),

@@ -203,6 +203,7 @@ struct wl_mg {
     std::vector<wl_level_desc> lev;
     Scratch sc;
     std::vector<void *> rowc;            // per level: row constants of L and iD (k_lrow), RC_N values per (j,k) row; D==3 only
+    unsigned char *dirty = nullptr;      // level-0 row flags of wl_mg_update_changed
     int alloc_rowc() {
         const size_t es = t == WL_F32 ? 4 : 8;
         rowc.assign(nlev, nullptr);
@@ -216,6 +217,8 @@ struct wl_mg {
     void free_scratch() {
         for (void *p : rowc) if (p) (void)hipFree(p);
         rowc.clear();
+        if (dirty) (void)hipFree(dirty);
+        dirty = nullptr;
     }
 };
 struct wl_flow {
@@ -231,6 +234,8 @@ struct wl_flow {
     int *rowcount = nullptr;
     long *rowoff = nullptr;
     unsigned char *touched = nullptr, *prev = nullptr;
+    unsigned char *changed = nullptr;   // rows whose coefficient arrays the last native measure! rewrote (touched now or before)
+    bool changed_valid = false;
     bool prev_valid = false;            // `prev` describes the arrays' current content (else: rewrite every row)
     long nband = -1;                    // result of the last wl_measure_rows (-1: none pending)
 };
@@ -245,12 +250,14 @@ template <class T> static LevelT<T> lvl(const wl_mg *m, int l) {
 }
 
 // ------------------------------------------------------------------------------------------ MG orchestration
-template <class T, int D> static int mg_update(wl_mg *m) {
+// dirty (optional, D == 3): flags of the level-0 x-rows whose D / iD / row constants can have changed (see
+// wl_mg_update_changed); every other row of level 0 keeps what it has.  Levels >= 1 are rebuilt in full (1/8, 1/64 ...).
+template <class T, int D> static int mg_update(wl_mg *m, const unsigned char *dirty = nullptr) {
     {
         LevelT<T> p = lvl<T>(m, 0);
-        WL_TRY((op_set_diag<T, D>(p.g, p.D, p.iD, p.L)));
+        WL_TRY((op_set_diag<T, D>(p.g, p.D, p.iD, p.L, dirty)));
         WL_TRY((halo_exchange<T>(p.g, p.iD, 1, 1)));   // z-slab: the fused smoother evaluates r*iD in the halo planes
-        if (D == 3 && m->rowc[0]) WL_TRY((op_lrow<T>(p.g, p.L, p.iD, (T *)m->rowc[0])));
+        if (D == 3 && m->rowc[0]) WL_TRY((op_lrow<T>(p.g, p.L, p.iD, (T *)m->rowc[0], dirty)));
     }
     for (int l = 1; l < m->nlev; ++l) {
         LevelT<T> a = lvl<T>(m, l), b = lvl<T>(m, l - 1);
@@ -611,6 +618,7 @@ static int measure_alloc(wl_flow *a, size_t nrows) {
     WL_HIP(hipMalloc((void **)&a->rowoff, (nrows + 1) * sizeof(long)));
     WL_HIP(hipMalloc((void **)&a->touched, nrows));
     WL_HIP(hipMalloc((void **)&a->prev, nrows));
+    WL_HIP(hipMalloc((void **)&a->changed, nrows));
     return 0;
 }
 template <class T, int D> static int measure_rows(wl_flow *a, const wl_body_desc *body, double eps, int64_t *nband) {
@@ -656,6 +664,10 @@ template <class T, int D> static int measure_fill(wl_flow *a, const wl_body_desc
     hipLaunchKernelGGL((k_rowflags_touched<D>), dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, ctx().stream, g,
                        (const unsigned char *)a->touched, a->rowbuf, a->d.perdir_mask);
     WL_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_rows_changed, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, ctx().stream, (const unsigned char *)a->touched,
+                       (const unsigned char *)a->prev, !a->prev_valid, a->changed, (long)nrows);
+    WL_HIP(hipGetLastError());
+    a->changed_valid = true;
     WL_HIP(hipMemcpyAsync(a->prev, a->touched, nrows, hipMemcpyDeviceToDevice, ctx().stream));
     WL_TRY(flow_compact_busy(a, g, D));
     a->prev_valid = true;
@@ -925,6 +937,21 @@ int wl_mg_destroy(wl_mg *m) {
     if (!m || level < 0 || level >= m->nlev) return fail(WL_E_ARG, "bad level", __FILE__, __LINE__)
 
 int wl_mg_update(wl_mg *m) { WL_MG_DISPATCH((mg_update<T, DD>(m))); }
+int wl_mg_update_changed(wl_mg *m, const wl_flow *a) {
+    if (!m || !a) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);
+    const wl_grid &gm = m->lev[0].g, &gf = a->d.g;
+    const bool usable = a->changed_valid && a->changed && m->D == 3 && gf.D == 3 && gm.n[0] == gf.n[0] && gm.n[1] == gf.n[1] &&
+                        gm.n[2] == gf.n[2] && m->lev[0].L == a->d.mu0 && !m->rowc.empty() && m->rowc[0];
+    if (!usable) return wl_mg_update(m);
+    const long nrows = (long)gm.n[1] * gm.n[2];
+    if (!m->dirty) WL_HIP(hipMalloc((void **)&m->dirty, (size_t)nrows));
+    // D, iD and the row constants of row (j,k) read L of the rows (j,k), (j+1,k), (j,k+1)
+    hipLaunchKernelGGL(k_rows_dirty, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, ctx().stream, (const unsigned char *)a->changed,
+                       m->dirty, gm.n[1], gm.n[2]);
+    WL_HIP(hipGetLastError());
+    const unsigned char *dirty = m->dirty;
+    WL_MG_DISPATCH((mg_update<T, DD>(m, dirty)));
+}
 int wl_mg_mult(wl_mg *m, int level, void *x) {
     WL_LEVEL_OK();
     WL_MG_DISPATCH((op_mult<T, DD>(lvl<T>(m, level), (T *)x, m->permask)));
@@ -1010,11 +1037,13 @@ int wl_flow_destroy(wl_flow *a) {
     if (a->rowoff) (void)hipFree(a->rowoff);
     if (a->touched) (void)hipFree(a->touched);
     if (a->prev) (void)hipFree(a->prev);
+    if (a->changed) (void)hipFree(a->changed);
     delete a;
     return 0;
 }
 int wl_flow_update(wl_flow *a) {
     if (!a) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);
+    a->changed_valid = false;   // the arrays were rewritten by the caller: nothing is known about which rows changed
     WL_DISPATCH(a->t, a->d.g.D, (flow_update<T, DD>(a)));
 }
 int wl_measure_rows(wl_flow *a, const wl_body_desc *body, double eps, int64_t *nband) {

@@ -258,4 +258,21 @@ __global__ __launch_bounds__(256) void k_rowflags_touched(G g, const unsigned ch
     flags[row] = fre ? 1 : 0;
 }
 
+// rows whose coefficient arrays this measure! rewrote: touched now or at the previous measure! (all of them the first time)
+__global__ __launch_bounds__(256) static void k_rows_changed(const unsigned char *touched, const unsigned char *prev, bool all,
+                                                            unsigned char *changed, long nrows) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r < nrows) changed[r] = (all || touched[r] || prev[r]) ? 1 : 0;
+}
+// level-0 rows whose D / iD / row constants read a changed row of L: the row itself and its lower y and z neighbours
+__global__ __launch_bounds__(256) static void k_rows_dirty(const unsigned char *changed, unsigned char *dirty, int n1, int n2) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= (long)n1 * n2) return;
+    const int j = (int)(r % n1), k = (int)(r / n1);
+    bool d = changed[r] != 0;
+    if (j + 1 < n1) d = d || changed[r + 1];
+    if (k + 1 < n2) d = d || changed[r + n1];
+    dirty[r] = d ? 1 : 0;
+}
+
 }  // namespace wl

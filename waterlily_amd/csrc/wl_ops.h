@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_bc_vec_all(G g, T *a, T A0, T A1, T A2,
     const unsigned q2 = pos / ext1, q1 = pos - q2 * ext1;
     int idx[3] = {0, 0, 0};   // GLOBAL indices
     idx[e1] = (int)q1 + (e1 == 2 ? g.zlo + g.kz0 : 0);
-    if (e2 >= 0) idx[e2] = (int)q2 + (e2 == 2 ? g.zlo + g.kz0 : 0);
+    if constexpr (D > 2) idx[e2] = (int)q2 + (e2 == 2 ? g.zlo + g.kz0 : 0);
     idx[d] = pl == 0 ? 0 : (pl == 1 ? 1 : ng[d] - 1);
     if (D > 2 && d == 2) {   // z planes: only the rank that owns them (nobody on a periodic ring: halo exchange fills them)
         const int kl = idx[2] - g.kz0;
@@ -917,11 +917,14 @@ _Pragma("unroll")
 
 // ------------------------------------------------------------------------------------------ Poisson.jl
 // set_diag!  src/Poisson.jl:42-54 (the two @inside loops fused; same values)
+// rows (optional, D == 3): per x-row flags (j + n1*k); only flagged rows are recomputed (update! after a measure! that
+// rewrote a known set of rows of L)
 template <class T, int D>
-int op_set_diag(const G &g, T *Dg, T *iD, const T *L) {
+int op_set_diag(const G &g, T *Dg, T *iD, const T *L, const unsigned char *rows = nullptr) {
     const G gg = g;
     const T eps2 = (T)2 * Lim<T>::eps;
     return launch_range(WL_K_SETDIAG, r_inside(g), [=] __device__(int i, int j, int k) {
+        if (rows && !rows[j + gg.n[1] * k]) return;   // wave-uniform: a wavefront never spans two rows
         const long I = gg.at(i, j, k);
         T s = 0;
 _Pragma("unroll")

@@ -533,11 +533,12 @@ inline int launch_rowvec(int kclass, const G &g, LD ld, ST st, const T *rowc, do
 //   Ly[i,j] == Ly[i,j+1] == Lz[i,k] == Lz[i,k+1] == c for every interior i, and iD[i] == idc for i = 2..n0-3
 // (the two end cells have a different diagonal when the boundary faces are not c), else NaN; layout: RC_N above.
 template <class T>
-__global__ __launch_bounds__(256) void k_lrow(G g, const T *__restrict__ L, const T *__restrict__ iD, T *rowc) {
+__global__ __launch_bounds__(256) void k_lrow(G g, const T *__restrict__ L, const T *__restrict__ iD, T *rowc, const unsigned char *rows) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long nrows = (long)g.n[1] * g.n[2];
     if (row >= nrows) return;
+    if (rows && !rows[row]) return;   // only the flagged rows are re-examined (their constants are rewritten)
     const int j = (int)(row % g.n[1]), k = (int)(row / g.n[1]);
     const T nan = __builtin_nanf("");
     T c = nan, idc = nan;
@@ -568,10 +569,10 @@ __global__ __launch_bounds__(256) void k_lrow(G g, const T *__restrict__ L, cons
         rc[6] = rc[7] = (T)0;
     }
 }
-template <class T> inline int op_lrow(const G &g, const T *L, const T *iD, T *rowc) {
+template <class T> inline int op_lrow(const G &g, const T *L, const T *iD, T *rowc, const unsigned char *rows = nullptr) {
     const long nrows = (long)g.n[1] * g.n[2];
     Prof p(WL_K_MISC, g.cells());
-    hipLaunchKernelGGL((k_lrow<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ctx().stream, g, L, iD, rowc);
+    hipLaunchKernelGGL((k_lrow<T>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ctx().stream, g, L, iD, rowc, rows);
     return (int)hipGetLastError();
 }
 

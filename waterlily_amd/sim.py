@@ -509,9 +509,13 @@ class MultiLevelPoisson(_PoissonBase):
         self._create(levels, perdir)
 
 
-def update(p) -> None:
-    """Poisson.jl:46 / MultiLevelPoisson.jl:62-68"""
-    check(_lib.lib().wl_mg_update(p._h))
+def update(p, flow: Optional["Flow"] = None) -> None:
+    """Poisson.jl:46 / MultiLevelPoisson.jl:62-68.  flow: the Flow whose mu0 is p.L -- after a native measure! of it only
+    the rows that measure! rewrote are revisited on the finest level (same values; wl_mg_update_changed)."""
+    if flow is not None and hasattr(p, "_h") and hasattr(flow, "_h"):
+        check(_lib.lib().wl_mg_update_changed(p._h, flow._h))
+    else:
+        check(_lib.lib().wl_mg_update(p._h))
 
 
 def mult(p, x: torch.Tensor) -> torch.Tensor:
@@ -694,7 +698,7 @@ def measure(sim: Simulation, t=None) -> None:
     t = float(np.sum(np.asarray(sim.flow.dt, dtype=np.float64))) if t is None else t
     measure_flow(sim.flow, sim.body, t=t, eps=sim.eps, geometry=sim.geometry)
     sim._band = None
-    update(sim.pois)
+    update(sim.pois, sim.flow)
 
 
 def sim_step(sim: Simulation, t_end=None, *, remeasure=True, max_steps=None, verbose=False) -> None:
