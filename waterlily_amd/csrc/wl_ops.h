@@ -954,22 +954,34 @@ int op_mult(const LevelT<T> &p, T *x, int permask) {
 template <class T> struct ResidualDivEpi {
     static constexpr bool HAS_LD = true;
     using VA = VecA<T>;
-    using Dat = FaceDat<T>;
+    struct Dat { VA x0, y0, y1, z1; T xr; };   // the face values of plane k except the lower z face, which is carried
+    using Carry = VA;                          // u_z of plane k (the upper z face of plane k-1's cells: loaded once)
     G gu; const T *u; const T *iD; T *r; int n0;
-    __device__ __forceinline__ Dat ld(long o, int j, int k) const { return face_load<T>(gu, u, o, j, k); }
+    __device__ __forceinline__ Dat ld(long o, int i, int, int) const {
+        Dat d;
+        d.x0 = VA::load(u + o);
+        d.xr = (T)0;
+        if ((threadIdx.x & 63) == 63 || i + VA::V > n0 - 2) d.xr = u[o + VA::V];        // the cell beyond this lane's vector
+        d.y0 = VA::load(u + o + gu.sc); d.y1 = VA::load(u + o + gu.sc + gu.s[1]);
+        d.z1 = VA::load(u + o + 2 * gu.sc + gu.s[2]);
+        return d;
+    }
+    __device__ __forceinline__ Carry first(long o, int, int) const { return VA::load(u + o + 2 * gu.sc); }
+    __device__ __forceinline__ Carry next(const Dat &d) const { return d.z1; }
     template <class RKT>
-    __device__ __forceinline__ void operator()(long o, int i, int, int, const VA &ax, const VA &, const Dat &d, const RKT &rk, double *acc,
-                                               const Pre &) const {
+    __device__ __forceinline__ void operator()(long o, int i, int, int, const VA &ax, const VA &, const Dat &d, const Carry &z0, const RKT &rk,
+                                               double *acc, const Pre &) const {
         const VA id = row_iD<T>(rk, iD, o, i, n0);
-        T xu[VA::V];
-        face_xup<T>(gu, d, i, xu);
+        T nxt = lane_dn1(d.x0.v[0]);
+        if ((threadIdx.x & 63) == 63 || i + VA::V > n0 - 2) nxt = d.xr;
         VA rv;
 _Pragma("unroll")
         for (int v = 0; v < VA::V; ++v) {
+            const T xu = (v == VA::V - 1) ? nxt : d.x0.v[v == VA::V - 1 ? v : v + 1];
             T s = 0;
-            s += xu[v] - d.x0.v[v];
+            s += xu - d.x0.v[v];
             s += d.y1.v[v] - d.y0.v[v];
-            s += d.z1.v[v] - d.z0.v[v];
+            s += d.z1.v[v] - z0.v[v];
             rv.v[v] = (id.v[v] == 0) ? (T)0 : s - ax.v[v];
             acc[0] += (double)rv.v[v];
         }

@@ -262,11 +262,18 @@ template <class T> struct SrcProlong {        // e[I] = coarse x[down(I)] inside
     template <class RKT> __device__ __forceinline__ T sxf(T a, const RKT &, long, int) const { return a; }
 };
 
-// An epilogue may bring its own operand loader (a functor with HAS_LD, `Dat ld(o, j, k)` and
-// `operator()(o, i, j, k, Ae, e, dat, rk, acc, pre)`): ld is called where ea / eb are requested, its result reaches the
+// An epilogue may bring its own operand loader (a functor with HAS_LD, `Dat ld(o, i, j, k)` and
+// `operator()(o, i, j, k, Ae, e, dat, carry, rk, acc, pre)`): ld is called where ea / eb are requested, its result reaches the
 // epilogue at the end of the iteration (op_residual with the divergence evaluated on the fly).  Lambdas have none.
-template <class E, class = void> struct EpiLd { static constexpr bool ON = false; struct Dat {}; };
-template <class E> struct EpiLd<E, std::enable_if_t<E::HAS_LD>> { static constexpr bool ON = true; using Dat = typename E::Dat; };
+// The loader may also keep one value per row from plane to plane (`Carry first(o, j, k0)` before the first plane,
+// `Carry next(dat)` after each): an operand of plane k+1 that the epilogue of plane k has already loaded (the upper z face
+// of a face difference is the lower one of the next plane).
+template <class E, class = void> struct EpiLd { static constexpr bool ON = false; struct Dat {}; struct Carry {}; };
+template <class E> struct EpiLd<E, std::enable_if_t<E::HAS_LD>> {
+    static constexpr bool ON = true;
+    using Dat = typename E::Dat;
+    using Carry = typename E::Carry;
+};
 
 // One launch of the 7-point kernel.  R rows per thread.  ea / eb: optional epilogue operand arrays, loaded next to the
 // stencil operands (requested at the top of the iteration, consumed by the epilogue at its end).
@@ -342,6 +349,11 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
             em[q] = src.xf(a, rkm, cq + sz * (k0 - 1), i);
             ec[q] = src.xf(c, rk0[q], cq + sz * k0, i);
         }
+        typename EpiLd<EPI>::Carry cy[R];
+        if constexpr (EpiLd<EPI>::ON) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) cy[q] = epi.first(col + q * sy + sz * k0, jb + q, k0);
+        }
         Fly A, B;
         request(A, k0);
 
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
                 if (SRC::EA_IS_RAW) av[q] = rawc[q];
                 else if (ea) av[q] = VA::load(ea + ok + q * sy);
                 if (eb) bv[q] = VA::load(eb + ok + q * sy);
-                if constexpr (EpiLd<EPI>::ON) ex[q] = epi.ld(ok + q * sy, jb + q, k);
+                if constexpr (EpiLd<EPI>::ON) ex[q] = epi.ld(ok + q * sy, i, jb + q, k);
             }
             request(nxt, kn);
             // ---- (2)+(3) in two copies: every row involved in this plane is coefficient-uniform (no L / iD load can occur),
@@ -412,7 +424,7 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
                         s += em[q].v[v] * lz0.v[v] + ep[q].v[v] * lz1.v[v];
                         ae.v[v] = s;
                     }
-                    if constexpr (EpiLd<EPI>::ON) epi(o, i, jb + q, k, ae, ec[q], ex[q], rc, acc, pre);
+                    if constexpr (EpiLd<EPI>::ON) { epi(o, i, jb + q, k, ae, ec[q], ex[q], cy[q], rc, acc, pre); cy[q] = epi.next(ex[q]); }
                     else epi(o, i, jb + q, k, ae, ec[q], (ea || SRC::EA_IS_RAW) ? av[q] : ec[q], eb ? bv[q] : ec[q], rc, acc, pre);
                 }
 #pragma unroll
