@@ -1,6 +1,6 @@
 set -e
-( while true; do sleep 50; echo "[alive] $(date +%T)"; done ) &
-HB=$!
-timeout -k 10 900 python -m pytest tests/test_hip_parity.py -q -m gpu -x -k "c3_full_size_512" --durations=3 > gpurun_out/r2_t21.log 2>&1 || { kill $HB; tail -40 gpurun_out/r2_t21.log | cut -c1-600; exit 1; }
-kill $HB
-tail -8 gpurun_out/r2_t21.log
+(rocm-smi --showclocks --showperflevel --showpower --showmaxpower --showmemorypartition --showcomputepartition --showtemp 2>&1 | head -60) > gpurun_out/smi_before.log || true
+python tools/series.py 512 24 pcg_direction > gpurun_out/series_c.log 2>&1; tail -4 gpurun_out/series_c.log
+(rocm-smi --showclocks --showpower --showtemp 2>&1 | head -40) > gpurun_out/smi_after.log || true
+cat gpurun_out/smi_before.log | cut -c1-160
+echo ---- ; cat gpurun_out/smi_after.log | cut -c1-160

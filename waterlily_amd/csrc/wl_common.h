@@ -444,13 +444,8 @@ inline int halo_end() {
 // no trip through the LDS crossbar (ds_bpermute) and no lgkmcnt wait behind it.  lane_up1(x): lane i receives lane i-1's
 // x (== __shfl_up(x,1)); lane_dn1(x): lane i receives lane i+1's (== __shfl_down(x,1)).  Lane 0 / lane 63 (and lanes
 // whose source lane is inactive) receive 0: callers overwrite those lanes with the value beyond the wavefront.
-#ifdef WL_NO_DPP   // (A/B builds only)
-__device__ __forceinline__ int dpp_up1(int v) { return __shfl_up(v, 1, 64); }
-__device__ __forceinline__ int dpp_dn1(int v) { return __shfl_down(v, 1, 64); }
-#else
-__device__ __forceinline__ int dpp_up1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_dn1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
-#endif
+__device__ __forceinline__ int dpp_up1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+__device__ __forceinline__ int dpp_dn1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
 __device__ __forceinline__ float lane_up1(float x) { return __builtin_bit_cast(float, dpp_up1(__builtin_bit_cast(int, x))); }
 __device__ __forceinline__ float lane_dn1(float x) { return __builtin_bit_cast(float, dpp_dn1(__builtin_bit_cast(int, x))); }
 __device__ __forceinline__ double lane_up1(double x) {
