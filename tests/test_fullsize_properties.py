@@ -149,19 +149,20 @@ def test_rows_per_thread_same_bits(S, flow, N):
 def test_traffic_saving_switches_do_not_change_a_bit(S, N):
     """The kernels that move fewer bytes than the dense algorithm -- row constants instead of L/iD in coefficient-
     uniform rows (option 9), x += alpha*eps deferred to the direction kernel (8), z' = r*iD recomputed instead of
-    stored (13), body-free rows in BDIM! (3), the chained x/=dt ; x*=dt' pass (14), the shared-flux conv_diff! kernel (18) -- evaluate the same expressions: three steps of the sphere case give
+    stored (13), z = A*eps formed a second time by the update kernel instead of stored (19), body-free rows in BDIM! (3), the chained x/=dt ; x*=dt' pass (14), the shared-flux conv_diff! kernel (18, 20), its x-ghost launch (21), div(u)
+    formed inside residual! (22), the x planes of BC! written by the producing kernel (23) -- evaluate the same expressions: three steps of the sphere case give
     bit-identical u and p with all of them off."""
     import bench
     sims = []
     for on in (1, 0):
-        for key in (3, 8, 9, 13, 14, 18, 20):
-            S.set_option(key, on)
+        for key in (3, 8, 9, 13, 14, 18, 19, 20, 21, 22, 23):
+            S.set_option(key, (2 if on else 0) if key == 19 else on)     # (19: 2 = on every level, also the 512^3 one)
         try:
             sim = bench.sphere((N, N, N), T)
             for _ in range(3):
                 S.sim_step(sim, remeasure=False)
         finally:
-            for key in (3, 8, 9, 13, 14, 18, 20):
+            for key in (3, 8, 9, 13, 14, 18, 19, 20, 21, 22, 23):
                 S.set_option(key, 1)
         sims.append(sim)
     a, b = sims

@@ -230,6 +230,7 @@ def test_pcg_vcycle_solver(T, Ng, rows, request):
     S.set_option(4, rows)
     request.addfinalizer(lambda: S.set_option(4, 0))
     po, ph = make_pois(Ng, T, O.MultiLevelPoisson, S.MultiLevelPoisson)
+    z0 = po.z.copy(order="F")
     O.residual(po)
     S.residual(ph)
     n_o, n_h = O.pcg(po), S.pcg(ph)
@@ -240,6 +241,10 @@ def test_pcg_vcycle_solver(T, Ng, rows, request):
     S.Vcycle(ph)
     same(lev_h(ph).r, lev_o(po).r, exact=False, tol=rtol(T))
     same(ph.x, po.x, exact=False, tol=rtol(T))
+    # z is pcg!'s scratch: the reference leaves A*eps in it, the HIP path (which never stores A*eps)
+    # leaves it alone; a solve starts from a source term the caller has set
+    po.z[...] = z0
+    S.upload(ph.z, z0)
     O.solver(po)
     S.solver(ph)
     assert po.n == ph.n
@@ -327,6 +332,27 @@ def test_uniform_rows_are_skipped_exactly(T):
     assert np.array_equal(S.to_host(ph.x), S.to_host(ph0.x))
     assert np.array_equal(S.to_host(lev_h(ph).r), S.to_host(lev_h(ph0).r))
     same(ph.x, po.x, exact=False, tol=10 * rtol(T))
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_pcg_without_stored_z_bit_exact(T):
+    """wl_set_option(19): pcg!'s update kernel forms z = A*eps a second time (7-point kernel over eps) instead of reading
+    the z the mult kernel stored.  Same expression on the same operands => x and r after the whole solver are
+    bit-identical to the run that stores z; both match the oracle."""
+    res = []
+    for on in (2, 0):
+        S.set_option(19, on)
+        try:
+            po, ph, _ = _blob_system(T, O.MultiLevelPoisson, S.MultiLevelPoisson)
+            S.solver(ph)
+        finally:
+            S.set_option(19, 1)
+        res.append(ph)
+    O.solver(po)
+    assert res[0].n == res[1].n == po.n
+    assert np.array_equal(S.to_host(res[0].x), S.to_host(res[1].x))
+    assert np.array_equal(S.to_host(lev_h(res[0]).r), S.to_host(lev_h(res[1]).r))
+    same(res[0].x, po.x, exact=False, tol=10 * rtol(T))
 
 
 @pytest.mark.parametrize("T", TYPES)

@@ -1235,6 +1235,15 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     // z' = r*iD (:136) is not stored (wl_set_option(13), default on): the direction kernel recomputes it from r and iD
     // (iD is a row constant away from the body), one array write + one read less per iteration; z keeps A*eps.
     const bool zrec = ctx().opt[13] != 0;
+    // z = A*eps is not stored either (wl_set_option(19); 3-D vector kernels): the update kernel is a second 7-point kernel
+    // over eps that forms the same A*eps again (same expression, same operands => same bits) and applies
+    // r -= alpha*(A*eps) in its epilogue.  Per iteration one array write (mult) and one array read (update) are replaced
+    // by a second read of eps (with its halo rows and planes).  Measured: 512^3 mult 0.303 -> 0.224 ms but update
+    // 0.344 -> 0.449 ms (the 7-point form of the update runs at 4.1 TB/s, with one or two rows per thread): no gain; 256^3 as the finest level: -2.5 % per
+    // step.  Default (1): levels below 2^26 cells; 2 = every level; 0 = never.
+    bool zst = false;
+    if constexpr (D == 3)
+        zst = (ctx().opt[19] >= 2 || (ctx().opt[19] == 1 && R.count() < (1L << 26))) && ctx().opt[5] != 0 && zrec && stencil7_ok<T>(p.g);
     // No finalize launches (wl_set_option(15), default on; single rank, default kernel forms): the dot products z.eps and
     // r.z' are finished by the NEXT kernel (every workgroup sums the <= 1024 partials and applies the scalar logic, Gate
     // kind 1..3), the state travels through st->slots; only the last update keeps its finalize (it publishes the state).
@@ -1323,7 +1332,7 @@ _Pragma("unroll")
                 gate_mult.eps10 = (double)eps10; gate_mult.f32 = f32;
                 rcv = launch_stencil7_halo<T, 1>(WL_K_PCG_MULT, p.g, p.eps, SrcArray<T>{p.eps}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
                     [=] __device__(long o, int, int, int, const VA &ae, const VA &ec, const VA &, const VA &, const auto &, double *acc, const Pre &) {
-                    ae.store(q.z + o);
+                    if (!zst) ae.store(q.z + o);
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];
                 }, PA, &np, gate_mult);
@@ -1362,7 +1371,36 @@ _Pragma("unroll")
             gate_upd.kind = 2; gate_upd.part = gp; gate_upd.np = gn; gate_upd.in = &st->slots[cur]; gate_upd.out = &st->slots[cur ^ 1];
         }
         gate_upd.eps10 = (double)eps10; gate_upd.f32 = f32;
-        if (vec) {
+        if constexpr (D == 3) {
+            if (zst) {   // 7-point kernel over eps: Ae == the z the mult kernel would have stored; a = r, b = x (when x is due)
+                auto upd_epi = [=] __device__(long o, int i, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, const auto &rk, double *acc, const Pre &pre) {
+                    const T alpha = (T)pre.s0;
+                    VA rr = r0;
+                    if (xnow) {
+                        VA xv = x0;
+_Pragma("unroll")
+                        for (int v = 0; v < VA::V; ++v) xv.v[v] += alpha * ec.v[v];
+                        xv.store(q.x + o);
+                    }
+_Pragma("unroll")
+                    for (int v = 0; v < VA::V; ++v) rr.v[v] = rr.v[v] - alpha * ae.v[v];
+                    rr.store(q.r + o);
+                    if (!last) {
+                        const VA id = row_iD<T>(rk, q.iD, o, i, n0);
+_Pragma("unroll")
+                        for (int v = 0; v < VA::V; ++v) { const T zn = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zn; }
+                    } else if (want_r2) {
+_Pragma("unroll")
+                        for (int v = 0; v < VA::V; ++v) acc[0] += (double)rr.v[v] * (double)rr.v[v];
+                    }
+                };
+                const T *xin = xnow ? (const T *)q.x : (const T *)nullptr;
+                rvu = launch_stencil7<T, 1>(WL_K_PCG_UPDATE, p.g, SrcArray<T>{p.eps}, p.L, p.rowc, (const T *)q.r, xin, upd_epi, PB, &np, gate_upd);
+                if (rvu != 0) return rvu > 0 ? rvu : fail(WL_E_STATE, "pcg: 7-point update kernel rejected", __FILE__, __LINE__);
+                if (infin) cur ^= 1;
+            }
+        }
+        if (vec && rvu != 0) {
             struct UD { VA r, z, x, e; };
             rvu = launch_rowvec<T, 1, true>(WL_K_PCG_UPDATE, p.g,
                 [=] __device__(long o, int, int, const Pre &) {
