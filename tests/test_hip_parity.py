@@ -632,6 +632,32 @@ def test_ref_impulsive_flow():  # maintests.jl:172-180
     assert O.L2(u[:, :, 0] - np.float32(U[0])) < 2e-5 and O.L2(u[:, :, 1] - np.float32(U[1])) < 1e-5
 
 
+def test_ref_increasing_body_force():  # maintests.jl:280-302 ("Flow.jl with increasing body force")
+    N, jerk = 8, 4
+    s = S.Simulation((N, N), (math.sqrt(N), 0.0), N, nu=0.001, g=lambda i, t: t * jerk if i == 0 else 0.0, dt=0.001,
+                     perdir=(0,), T=np.float64)
+    S.sim_step(s, 1.0)
+    u = S.to_host(s.flow.u)
+    uFinal = math.sqrt(N) + 0.5 * jerk * S.time(s.flow) ** 2          # u_x0 + integral of jerk*t dt
+    assert O.L2(u[:, :, 0] - uFinal) < 1e-4 and O.L2(u[:, :, 1] - 0) < 1e-4
+
+
+def test_ref_circle_in_accelerating_flow():  # maintests.jl:304-316
+    radius, H = 32, 16
+    c = float(H * radius)
+    tw = bodies.sphere(c, radius)
+    s = S.Simulation((radius * 2 * H, radius * 2 * H), lambda i, t: t if i == 0 else 0.0 * t, radius, U=1, body=tw.product,
+                     geometry="device", T=np.float32)
+    S.sim_step(s)
+    f = S.pressure_force(s) / (math.pi * s.L ** 2)
+    assert np.allclose(f, [-1, 0], atol=0.04)                          # added mass of the circle
+    u = S.to_host(s.flow.u)
+    assert u.max() / u[1, 1, 0] > 1.91                                 # ~2U at the shoulder
+    for _ in range(3):
+        S.sim_step(s)
+    assert all(n <= 2 for n in s.pois.n)
+
+
 def test_ref_periodic_TGV():  # maintests.jl:232-253
     L = 64
     k = 2 * math.pi / L
