@@ -195,8 +195,10 @@ int wl_mg_update_changed(wl_mg *m, const wl_flow *a);
  * Bodies defined by arbitrary closures stay on the host side of the ABI (waterlily_amd.body: torch).
  *   family WL_BODY_SPHERE: p = {c0, c1, c2, radius}  sdf = sqrt(sum(abs2, xi - c)) - radius   (circle when D == 2)
  *   family WL_BODY_TORUS : p = {c0, c1, c2, R, r}    sdf = norm((xi0-c0, norm((xi1-c1, xi2-c2)) - R)) - r   (D == 3)
+ *   family WL_BODY_PLATE : p = {a, thk}              sdf = norm(xi - (clamp(xi0,-a,a), 0[, 0])) - thk   (the reference's
+ *                                                    test plate, test/maintests.jl:375: a stadium / capsule about the xi0 axis)
  * Matrices are row-major 3x3 (the upper-left 2x2 block when D == 2). */
-enum { WL_BODY_SPHERE = 0, WL_BODY_TORUS = 1 };
+enum { WL_BODY_SPHERE = 0, WL_BODY_TORUS = 1, WL_BODY_PLATE = 2 };
 typedef struct wl_body_desc {
     int32_t family;
     int32_t identity_map;   /* != 0: xi = x (A, b, dA, db, Ainv are ignored; V = 0) */

@@ -66,7 +66,8 @@ def rotating_plate(radius):
         s, c = torch.sin(t / radius + 1), torch.cos(t / radius + 1)
         e = x - 2 * radius
         return torch.stack([c * e[0] + s * e[1], -s * e[0] + c * e[1]])
-    return Twin(AutoBody(_plate(radius), rotate), G.Body(G.Plate(radius - 2, 2.0), G.Rotate2D(2 * radius, 1 / radius, 1.0)))
+    return Twin(AutoBody(_plate(radius), rotate), G.Body(G.Plate(radius - 2, 2.0), G.Rotate2D(2 * radius, 1 / radius, 1.0)),
+                lambda D: B.Plate(radius - 2, 2.0, 2, map=B.rotation2d(2 * radius, 1 / radius, 1.0)))
 
 
 def bending_plate(radius):

@@ -691,6 +691,17 @@ def test_ref_moving_bodies():  # maintests.jl:391-412 (exitBC=false branch) + si
     S.sim_step(s)
     assert s.pois.n == [2, 1]
     assert float(s.flow.u.max()) > float(s.flow.V.max()) > 0
+    # non-uniform V doesn't break (:376-379, rotating plate) -- the closures through torch, then the native plate family
+    for body in (bodies.rotating_plate(radius).product, bodies.rotating_plate(radius).native(2)):
+        s = S.Simulation(nm, (0, 0), radius, U=1, body=body, nu=nu, T=np.float32)
+        S.sim_step(s)
+        assert s.pois.n == [2, 1]
+        assert 1 > s.flow.dt[-1] > 0.5
+    # divergent V doesn't break (:380-383, bending plate: a non-affine map, closures only)
+    s = S.Simulation(nm, (0, 0), radius, U=1, body=bodies.bending_plate(radius).product, nu=nu, T=np.float32)
+    S.sim_step(s)
+    assert s.pois.n == [2, 1]
+    assert 1.2 > s.flow.dt[-1] > 0.8
 
 
 def test_ref_hydrostatic_force():  # maintests.jl:341-346
@@ -753,6 +764,7 @@ def test_native_measure_matches_oracle(T):
              ((48, 32), bodies.sphere(15.0, 4.0), (0.0,)),
              ((48, 32), bodies.moving_circle(14.0, 6.0, v=3.0, a=2.0), (0.0, 0.5, 2.5)),
              ((40, 40), bodies.rotating_circle(9.0, 5.0, 20.0, 0.4, 1.0), (0.0, 1.7)),
+             ((32, 32), bodies.rotating_plate(8), (0.0, 0.6, 2.3)),
              ((m, m, m), bodies.moving_circle(12.0, 4.0, a=2.0, D=3), (0.3, 1.2))]
     eps = geom_tol(T)
     for dims, tw, times in cases:

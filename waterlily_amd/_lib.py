@@ -43,7 +43,7 @@ class BodyDesc(C.Structure):
                 ("b", C.c_double * 3), ("dA", C.c_double * 9), ("db", C.c_double * 3), ("Ainv", C.c_double * 9)]
 
 
-WL_BODY_SPHERE, WL_BODY_TORUS = 0, 1
+WL_BODY_SPHERE, WL_BODY_TORUS, WL_BODY_PLATE = 0, 1, 2
 
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)

@@ -181,6 +181,20 @@ class Torus(ParametricBody):
         super().__init__(sdf_closure, c + [R, r], map)
 
 
+class Plate(ParametricBody):
+    """norm(x - (clamp(x1,-a,a), 0[, 0])) - thk: the reference's test plate (test/maintests.jl:375), a stadium (2-D) or
+    capsule (3-D) of half-span `a` and half-thickness `thk` about the first axis of the mapped coordinates."""
+    family = 2
+
+    def __init__(self, a, thk, D: int, map: Optional[AffineMap] = None):
+        a, thk = float(a), float(thk)
+
+        def sdf_closure(x, t):
+            e0 = x[0] - torch.clamp(x[0], -a, a)
+            return torch.sqrt(e0 ** 2 + sum(x[i] ** 2 for i in range(1, D))) - thk
+        super().__init__(sdf_closure, [a, thk], map)
+
+
 def _as_points(x) -> Tuple[torch.Tensor, bool]:
     x = torch.as_tensor(np.asarray(x, dtype=np.float64)) if not isinstance(x, torch.Tensor) else x.to(torch.float64)
     single = x.ndim == 1

@@ -675,7 +675,8 @@ template <class T, int D> static int measure_fill(wl_flow *a, const wl_body_desc
 }
 static int check_body(const wl_body_desc *b, int D) {
     if (!b) return fail(WL_E_ARG, "null body", __FILE__, __LINE__);
-    if (b->family != WL_BODY_SPHERE && b->family != WL_BODY_TORUS) return fail(WL_E_ARG, "unknown body family", __FILE__, __LINE__);
+    if (b->family != WL_BODY_SPHERE && b->family != WL_BODY_TORUS && b->family != WL_BODY_PLATE)
+        return fail(WL_E_ARG, "unknown body family", __FILE__, __LINE__);
     if (b->family == WL_BODY_TORUS && D != 3) return fail(WL_E_ARG, "the torus family needs D == 3", __FILE__, __LINE__);
     return 0;
 }

@@ -1,7 +1,7 @@
 // wl_measure.h -- measure!(flow, body; t, eps) (src/Body.jl:31-53) for PARAMETRIC bodies as hand-written kernels.
 //
 // The reference evaluates user closures (sdf, map) with ForwardDiff inside its fill loop (src/AutoBody.jl:115-131).
-// Closures cannot cross a C ABI; a body whose sdf belongs to a closed-form family (sphere/circle, torus) composed with
+// Closures cannot cross a C ABI; a body whose sdf belongs to a closed-form family (sphere/circle, torus, plate) composed with
 // an affine map xi = A(t) x + b(t) (rigid translation / rotation / scaling) can: the host passes the family id, its
 // parameters and A, b, dA/dt, db/dt, A^-1 at the measured time (wl_body_desc), and the device evaluates
 //     d = sdf(xi), grad_x d = A^T grad_xi sdf,  m = |grad|, d /= m, n = grad / m,  V = -A^-1 (dA/dt x + db/dt)
@@ -52,6 +52,22 @@ template <int D> __device__ __forceinline__ double body_sdf(const BodyDev &B, co
         const double rho = sqrt(e0 * e0 + q * q);
         if (want_grad) { g[0] = e0 / rho; g[1] = (q / rho) * (e1 / s); g[D - 1] = (q / rho) * (e2 / s); }
         return rho - B.p[4];
+    }
+    if (B.family == WL_BODY_PLATE) {   // sqrt(sum(abs2, xi - (clamp(xi0,-a,a), 0[, 0]))) - thk   (maintests.jl:375)
+        const double a = B.p[0];
+        double e[D], s2 = 0;
+        e[0] = xi[0] - (xi[0] < -a ? -a : (xi[0] > a ? a : xi[0]));
+#pragma unroll
+        for (int c = 1; c < D; ++c) e[c] = xi[c];
+#pragma unroll
+        for (int c = 0; c < D; ++c) s2 += e[c] * e[c];
+        const double rho = sqrt(s2);
+        if (want_grad) {   // d e0/d xi0 = 1 - clamp' = 0 inside the span, 1 outside (0*e0/rho keeps the NaN of rho = 0)
+            g[0] = (fabs(xi[0]) > a) ? e[0] / rho : 0.0 * e[0] / rho;
+#pragma unroll
+            for (int c = 1; c < D; ++c) g[c] = e[c] / rho;
+        }
+        return rho - B.p[1];
     }
     // WL_BODY_SPHERE: sqrt(sum(abs2, xi - c)) - R
     double e[D], s2 = 0;
