@@ -43,6 +43,9 @@ def main():
             q = torch.sqrt((x[1] - cc) ** 2 + (x[2] - cc) ** 2) - Rm
             return torch.sqrt((x[0] - cc) ** 2 + q ** 2) - rm
         body, L, nu = AutoBody(sdf), Rm, Rm / 1000
+    elif "move" in case:   # parametric sphere drifting along z across the slab boundaries: native measure! kernels + the
+        from waterlily_amd import body as B                      # changed-rows update!(pois) every step
+        body, L, nu = B.Sphere(c, R, 3, map=B.translation(3, v=(0.2, 0.0, 0.9))), 2 * R, 2 * R / 500
     else:
         body, L, nu = AutoBody(lambda x, t: norm2(x - c) - R), 2 * R, 2 * R / 3700
     perdir = ()
@@ -66,8 +69,8 @@ def main():
         out["init_" + k] = float(np.max(np.abs(S.gather(getattr(sim.flow, k)) - S.to_host(getattr(ref.flow, k)))))
     nsteps = 3
     for _ in range(nsteps):
-        S.sim_step(ref, remeasure=False)
-        S.sim_step(sim, remeasure=False)
+        S.sim_step(ref, remeasure="move" in case)
+        S.sim_step(sim, remeasure="move" in case)
     out["n_ref"], out["n_slab"] = ref.pois.n, sim.pois.n
     out["dt_ref"], out["dt_slab"] = ref.flow.dt, sim.flow.dt
     for k in ("u", "p", "f"):

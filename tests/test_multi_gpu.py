@@ -81,7 +81,8 @@ def check(out, T):
 @pytest.mark.parametrize("nproc,case", [(2, "sphere_deep_f32"), (4, "sphere_long_deep_f32"), (2, "donut_deep_f64"),
                                         (2, "sphere_exit_deep_f32"), (2, "sphere_f32"),
                                         (2, "sphere_zper_deep_f32"), (4, "sphere_long_zper_deep_f64"),
-                                        (2, "sphere_yzper_accel_deep_f64"), (2, "sphere_yper_exit_accel_f32")])
+                                        (2, "sphere_yzper_accel_deep_f64"), (2, "sphere_yper_exit_accel_f32"),
+                                        (2, "sphere_move_deep_f32"), (4, "sphere_long_move_f64")])
 def test_slabs_match_undecomposed(nproc, case):
     out = run_workers("mg_worker.py", nproc, case)
     # "deep", 32^3 on 2 ranks: levels 32,16,8 (16,8,4 planes per rank) are slabs, 4^3 and 2^3 are replicated;
