@@ -206,6 +206,8 @@ def main():
     ncell_global = int(np.prod(dims))
     ncell = ncell_global // world            # cells per rank: threshold for "finest level" launches
     names = class_table(L)
+    if args.kernel is not None and (args.kernel not in names or args.kernel not in ALG_T):
+        raise SystemExit(f"--kernel {args.kernel}: not a priced kernel class (choose from {sorted(k for k in ALG_T if k in names)})")
 
     def sync():
         torch.cuda.synchronize()
@@ -282,7 +284,12 @@ def main():
         return rec
 
     roof = kernel_record(dominant, nl.value, nc.value, ms.value)
+    if roof is None:   # the class had no finest-level launch in the timed region: say so instead of failing after the run
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "launches": int(nl.value), "note": "no finest-level launch of this class was timed"}
     roof["uniform_row_fraction"] = phi
+    # (one extra step per class right after warm-up: a pcg! call that leaves early still enqueues its remaining kernels as
+    #  no-ops, so ms / launches here is NOT a per-kernel duration -- `avg_launch_ms` above and profiles/ are)
     roof["per_class_ms_one_step"] = {k: {"launches": v["launches"], "ms": v["ms"]} for k, v in per_class.items()}
     sm = per_class.get("smooth")
     pr = per_class.get("prolongate")

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 4
+#define WL_ABI_VERSION 5
 
 typedef enum wl_dtype { WL_F32 = 0, WL_F64 = 1 } wl_dtype;
 
@@ -160,11 +160,22 @@ int wl_mg_jacobi(wl_mg *m, int level, int it);
 int wl_mg_pcg(wl_mg *m, int level, int it, int *n_updates);
 /* L2(p) = r.r                         src/Poisson.jl:146 */
 int wl_mg_L2(wl_mg *m, int level, double *out);
+/* L∞(p) = maximum(abs, p.r)            src/Poisson.jl:147 (over inside(r): its ghost entries are zero) */
+int wl_mg_Linf(wl_mg *m, int level, double *out);
 /* Vcycle!(ml;l)                       src/MultiLevelPoisson.jl:70-82 */
 int wl_mg_vcycle(wl_mg *m, int level);
 /* solver!(p;tol,itmx)                 src/MultiLevelPoisson.jl:87-99 (src/Poisson.jl:162-172 for one
  * level).  n_iter receives the value the reference pushes onto `p.n`. */
 int wl_mg_solve(wl_mg *m, double tol, int itmx, int *n_iter);
+/* The pressure-solver log of the reference (`@log ", $n, $(L∞(p)), $r₂\n"`, src/Poisson.jl:164,167,
+ * src/MultiLevelPoisson.jl:90,94; macro and file format: src/util.jl:4-24).  wl_mg_log(m, 1) makes every later
+ * wl_mg_solve / wl_project / wl_mom_step on this hierarchy record one row {n, L∞(p), L₂(p)} for the initial residual
+ * (n = 0) and for each iteration -- two extra reductions and a host synchronisation per row, so it is off by default.
+ * wl_mg_log_read copies up to `cap` rows (3 doubles each, oldest first) into `rows`, returns the number of rows
+ * recorded since the last read in *n (which may exceed cap) and clears the record.  The host prints the "p" / "c"
+ * prefixes of src/Flow.jl:158,165 itself. */
+int wl_mg_log(wl_mg *m, int on);
+int wl_mg_log_read(wl_mg *m, double *rows, int cap, int *n);
 
 /* ------------------------------------------------------------------ Flow (src/Flow.jl:92-122) */
 typedef struct wl_flow_desc {
@@ -187,8 +198,11 @@ int wl_flow_update(wl_flow *a);
 /* update!(pois) after a native measure! (wl_measure_fill) of the flow whose mu0 is this hierarchy's L: on level 0 only the
  * x-rows that measure! rewrote (and their lower y / z neighbours, whose diagonal reads them) get D, iD and row constants
  * recomputed -- every other row holds the same values already; levels >= 1 are rebuilt in full.  Same results as
- * wl_mg_update (to which it falls back when the flow's last change was not a native measure!, or in 2-D). */
-int wl_mg_update_changed(wl_mg *m, const wl_flow *a);
+ * wl_mg_update (to which it falls back when the flow's last change was not a native measure!, or in 2-D).
+ * Periodic y / z: the last interior row also follows the first one (its upper ghost row is that row's periodic copy); a
+ * z-periodic ring of slabs takes the full update.  Consumes the flow's changed-row record: flags of several
+ * wl_measure_fill calls accumulate until this call (or wl_mg_update_changed of the same flow) has used them. */
+int wl_mg_update_changed(wl_mg *m, wl_flow *a);
 /* measure!(flow, body; t, eps)        src/Body.jl:31-53 for a PARAMETRIC body: an sdf family with closed-form gradient
  * (what ForwardDiff.gradient returns, src/AutoBody.jl:119) composed with an affine map xi = A x + b evaluated by the
  * host at the measured time together with its time derivative and inverse (AutoBody.jl:128-130: V = -J \ d(map)/dt).
@@ -307,6 +321,11 @@ int wl_prof_reset(void);
 int wl_prof_counts(int kclass, int64_t *launches, int64_t *cells);
 /* number of stencil launches since start-up that were split to overlap a z-slab halo exchange (comm stream) */
 int wl_prof_overlapped(int64_t *count);
+/* collectives issued by this rank since the last wl_prof_reset (z-slab runs; all zero without a communicator):
+ * out[0] all-reduces, out[1] halo exchanges (one grouped send/recv batch each), out[2] send/recv pairs inside them (one per
+ * component and neighbour side), out[3] all-gathers, out[4] bytes this rank sent in halo exchanges, out[5] bytes it
+ * contributed to all-gathers */
+int wl_prof_comm(int64_t out[6]);
 /* for the selected class: timed launches, their summed cells, summed milliseconds (synchronises) */
 int wl_prof_timed(int64_t *launches, int64_t *cells, double *ms);
 

@@ -23,7 +23,7 @@ def test_binding_covers_header():
 
 def test_abi_version_and_names():
     L = _lib.lib()
-    assert L.wl_abi_version() == 4
+    assert L.wl_abi_version() == 5
     assert L.wl_kernel_name(14) == b"pcg_mult_dot"
 
 

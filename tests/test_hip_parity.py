@@ -530,6 +530,17 @@ def test_c3_full_size_512_f32_against_the_oracle():
     check_step(so, sh, np.float32, 2)
 
 
+def test_c5_256_f64_torus_against_the_oracle():
+    """BASELINE config C5's case -- torus AutoBody, Float64, Re=1000 -- at 256^3 (the largest 3-D Float64 size the CPU oracle
+    steps in seconds): 2 steps, identical V-cycle counts and time steps, u within 1e-10 and p within 1e-9 of their maxima,
+    pressure force to 1e-8.  (C5 at its own size, 512^3: tests/test_fullsize_properties.py.)"""
+    m = 256
+    c, Rm, rm = m / 2, m / 4, m / 16
+    so, sh = pair((m, m, m), (1.0, 0.0, 0.0), Rm, nu=Rm / 1000, body=bodies.torus(c, Rm, rm), T=np.float64, geometry="device")
+    check_step(so, sh, np.float64, 2, utol=1e-10)
+    assert np.allclose(O.pressure_force(so), S.pressure_force(sh), rtol=1e-8, atol=1e-9)
+
+
 @pytest.mark.parametrize("T", TYPES)
 @pytest.mark.parametrize("dims", [(48, 32), (32, 32, 32)])
 def test_mom_step_dense_julia_layout(T, dims):
@@ -676,32 +687,78 @@ def test_ref_periodic_TGV():  # maintests.jl:232-253
     assert O.L2(u[:, :, 0] - ue[:, :, 0]) < 1e-4 and O.L2(u[:, :, 1] - ue[:, :, 1]) < 1e-4
 
 
-def test_ref_moving_bodies():  # maintests.jl:391-412 (exitBC=false branch) + sim_time stop rule :387-390
+@pytest.mark.parametrize("exitBC", [True, False])
+def test_ref_moving_bodies(exitBC):  # maintests.jl:391-412 (`for exitBC ∈ (true,false)`) + sim_time stop rule :387-390
     radius = 8
     nu = radius / 250
     nm = (4 * radius, 4 * radius)
-    s = S.Simulation(nm, (1, 0), radius, body=bodies.sphere(2.0 * radius, radius).product, nu=nu, T=np.float32)
+    kw = dict(nu=nu, T=np.float32, exitBC=exitBC)
+    s = S.Simulation(nm, (1, 0), radius, body=bodies.sphere(2.0 * radius, radius).product, **kw)
     assert S.sim_time(s) == 0
     S.sim_step(s, 0.1, remeasure=False)
     assert S.sim_time(s) >= 0.1 > sum(s.flow.dt[:-2]) * s.U / s.L
-    s = S.Simulation(nm, (1, 0), radius, body=bodies.moving_circle(2.0 * radius, radius, v=1.0).product, nu=nu, T=np.float32)
+    s = S.Simulation(nm, (1, 0), radius, body=bodies.moving_circle(2.0 * radius, radius, v=1.0).product, **kw)
     S.sim_step(s)
     assert np.allclose(S.to_host(s.flow.u)[:, radius - 1, 0], 1, rtol=1e-3)
-    s = S.Simulation(nm, (0, 0), radius, U=1, body=bodies.moving_circle(2.0 * radius, radius, a=2.0).product, nu=nu, T=np.float32)
+    s = S.Simulation(nm, (0, 0), radius, U=1, body=bodies.moving_circle(2.0 * radius, radius, a=2.0).product, **kw)
     S.sim_step(s)
     assert s.pois.n == [2, 1]
     assert float(s.flow.u.max()) > float(s.flow.V.max()) > 0
     # non-uniform V doesn't break (:376-379, rotating plate) -- the closures through torch, then the native plate family
     for body in (bodies.rotating_plate(radius).product, bodies.rotating_plate(radius).native(2)):
-        s = S.Simulation(nm, (0, 0), radius, U=1, body=body, nu=nu, T=np.float32)
+        s = S.Simulation(nm, (0, 0), radius, U=1, body=body, **kw)
         S.sim_step(s)
         assert s.pois.n == [2, 1]
         assert 1 > s.flow.dt[-1] > 0.5
     # divergent V doesn't break (:380-383, bending plate: a non-affine map, closures only)
-    s = S.Simulation(nm, (0, 0), radius, U=1, body=bodies.bending_plate(radius).product, nu=nu, T=np.float32)
+    s = S.Simulation(nm, (0, 0), radius, U=1, body=bodies.bending_plate(radius).product, **kw)
     S.sim_step(s)
     assert s.pois.n == [2, 1]
     assert 1.2 > s.flow.dt[-1] > 0.8
+
+
+@pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("dims", [(34, 18), (18, 18, 10)])
+def test_solver_log_and_Linf(T, dims):
+    """L∞(p) (Poisson.jl:147) and the rows of the reference's pressure-solver log (`@log ", $n, $(L∞(p)), $r₂"`,
+    MultiLevelPoisson.jl:90,94) from the overridden solver!: against the oracle's operators replayed in the order
+    solver! calls them (residual!, then Vcycle! + pcg! per iteration), same iteration count, r∞ and r₂ to rounding."""
+    Ng = tuple(dims)
+    D = len(Ng)
+    c = np.asfortranarray(rnd(Ng + (D,), T, 3, 0.2, 1.0))
+    O.BC(c, (0.0,) * D)
+    z0 = rnd(Ng, T, 4)
+    z0[O.inside(z0)] -= z0[O.inside(z0)].mean().astype(T)
+    xo, Lo, zo = O.zeros(Ng, T), c.copy(order="F"), z0.copy(order="F")
+    po = O.MultiLevelPoisson(xo, Lo, zo)
+    xh, Lh, zh = field(O.zeros(Ng, T), D), field(c, D), field(z0, D)
+    ph = S.MultiLevelPoisson(xh, Lh, zh)
+    S.solver_log(ph, True)
+    S.solver(ph)
+    rows = S.read_solver_log(ph)
+    # the oracle replay of MultiLevelPoisson.jl:87-99
+    p0 = po.levels[0]
+    O.residual(p0)
+    want = [(0, float(np.max(np.abs(p0.r))), O.L2p(p0))]
+    n = 0
+    while n < 32:
+        O.Vcycle(po)
+        O.pcg(p0)
+        n += 1
+        want.append((n, float(np.max(np.abs(p0.r))), O.L2p(p0)))
+        if want[-1][2] < 1e-4:
+            break
+    assert ph.n == [n] and len(rows) == len(want)
+    for got, w in zip(rows, want):
+        assert got[0] == w[0]
+        assert abs(got[1] - w[1]) <= 200 * rtol(T) * max(want[0][1], 1e-30) and abs(got[2] - w[2]) <= 200 * rtol(T) * max(want[0][2], 1e-30)
+    assert abs(S.Linf(ph) - want[-1][1]) <= 200 * rtol(T) * want[0][1]
+    txt = S.format_solver_log(rows, "p")
+    assert txt.startswith("p, 0, ") and txt.count("\n") == len(rows)
+    assert len(S.read_solver_log(ph)) == 0                    # read clears
+    S.solver_log(ph, False)
+    S.solver(ph)
+    assert len(S.read_solver_log(ph)) == 0
 
 
 def test_ref_hydrostatic_force():  # maintests.jl:341-346
@@ -820,13 +877,20 @@ def test_native_measure_matches_oracle(T):
 
 
 @pytest.mark.parametrize("T", TYPES)
-def test_update_of_changed_rows_equals_full_update(T):
+@pytest.mark.parametrize("perdir", [(), (1, 2)], ids=["walls", "yz-periodic"])
+def test_update_of_changed_rows_equals_full_update(T, perdir):
     """update!(pois) after a native measure! revisits, on the finest level, only the rows that measure! rewrote (plus the
     lower neighbours whose diagonal reads them): D, iD, the solver's behaviour and every field of a moving-body run are
-    bit-identical to the same run with the full update!."""
+    bit-identical to the same run with the full update!.  Periodic y / z: the body sits on the lower y / z faces and
+    moves along them, so the last interior rows -- whose upper ghost row is the periodic copy of the first interior row --
+    must follow the rows next to the opposite face."""
+    from waterlily_amd import body as B
     m = 40
-    mk = lambda: S.Simulation((m, m, m), (1.0, 0.0, 0.0), 8.0, body=bodies.moving_circle(14.0, 5.0, v=1.5, a=0.5, D=3).native(3),
-                              nu=0.05, T=T)
+    if perdir:
+        body = lambda: B.Sphere((14.0, 2.5, 3.0), 5.0, 3, map=B.translation(3, v=(1.5, 0.3, -0.2), a=(0.5, 0.0, 0.0)))
+    else:
+        body = lambda: bodies.moving_circle(14.0, 5.0, v=1.5, a=0.5, D=3).native(3)
+    mk = lambda: S.Simulation((m, m, m), (1.0, 0.0, 0.0), 8.0, body=body(), nu=0.05, T=T, perdir=perdir)
     a, b = mk(), mk()
     for _ in range(4):
         S.sim_step(a)                                   # measure! + update!(pois, flow): changed rows only
@@ -841,6 +905,30 @@ def test_update_of_changed_rows_equals_full_update(T):
     assert torch.equal(a.flow.u, b.flow.u) and torch.equal(a.flow.p, b.flow.p)
     for l in range(1, len(a.pois.levels)):
         assert torch.equal(a.pois.levels[l].L, b.pois.levels[l].L) and torch.equal(a.pois.levels[l].iD, b.pois.levels[l].iD), l
+
+
+def test_two_measures_before_one_update_keep_every_changed_row():
+    """measure_flow is public: two native measure! calls in a row (the body jumps twice) followed by ONE update!(pois, flow).
+    The rows the first call reset to (1,0,0) and the second did not touch must still be revisited: the changed-row record
+    accumulates until update! consumes it.  Result == the full update!."""
+    m = 40
+    T = np.float32
+    mk = lambda: S.Simulation((m, m, m), (1.0, 0.0, 0.0), 8.0, body=bodies.moving_circle(12.0, 4.0, v=1.0, D=3).native(3), nu=0.05, T=T)
+    a, b = mk(), mk()
+    for s in (a, b):
+        for t in (9.0, 18.0):                           # far jumps: three disjoint sets of rows
+            S.measure_flow(s.flow, s.body, t=t, eps=s.eps, geometry=s.geometry)
+    S.update(a.pois, a.flow)                            # changed rows of BOTH calls
+    S.update(b.pois)                                    # full
+    for k in ("D", "iD"):
+        assert torch.equal(getattr(a.pois.levels[0], k), getattr(b.pois.levels[0], k)), k
+    assert S.uniform_rows(a.pois, 0) == S.uniform_rows(b.pois, 0)
+    # and the record is consumed: a third measure! + update! is again equal to the full one
+    for s in (a, b):
+        S.measure_flow(s.flow, s.body, t=20.0, eps=s.eps, geometry=s.geometry)
+    S.update(a.pois, a.flow)
+    S.update(b.pois)
+    assert torch.equal(a.pois.levels[0].iD, b.pois.levels[0].iD) and S.uniform_rows(a.pois, 0) == S.uniform_rows(b.pois, 0)
 
 
 def _inside_mask(shape):

@@ -126,6 +126,9 @@ def lib() -> C.CDLL:
         "wl_mg_jacobi": (i, [vp, i, i]),
         "wl_mg_pcg": (i, [vp, i, i, ip]),
         "wl_mg_L2": (i, [vp, i, dp]),
+        "wl_mg_Linf": (i, [vp, i, dp]),
+        "wl_mg_log": (i, [vp, i]),
+        "wl_mg_log_read": (i, [vp, dp, i, ip]),
         "wl_mg_vcycle": (i, [vp, i]),
         "wl_mg_solve": (i, [vp, d, i, ip]),
         "wl_flow_create": (i, [C.POINTER(vp), i, C.POINTER(FlowDesc)]),
@@ -146,13 +149,14 @@ def lib() -> C.CDLL:
         "wl_prof_reset": (i, []),
         "wl_prof_overlapped": (i, [C.POINTER(i64)]),
         "wl_prof_counts": (i, [i, C.POINTER(i64), C.POINTER(i64)]),
+        "wl_prof_comm": (i, [C.POINTER(i64)]),
         "wl_prof_timed": (i, [C.POINTER(i64), C.POINTER(i64), dp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.wl_abi_version() != 4:
+    if L.wl_abi_version() != 5:
         raise WlError("libwlhip.so ABI version mismatch; rebuild it")
     _lib = L
     return L

@@ -26,10 +26,10 @@ struct RcclComm : Comm {
         ctx().err = std::string("rccl: ") + what + ": " + ncclGetErrorString(r);
         return WL_E_STATE;
     }
-    int allreduce(double *dev, int n, int op) override {
+    int do_allreduce(double *dev, int n, int op) override {
         return chk(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, nc, ctx().stream), "allreduce");
     }
-    int sendrecv(const void *slo, void *rlo, const void *shi, void *rhi, size_t bytes, int plo, int phi) override {
+    int do_sendrecv(const void *slo, void *rlo, const void *shi, void *rhi, size_t bytes, int plo, int phi) override {
         int rc = chk(ncclGroupStart(), "groupStart");
         if (rc) return rc;
         // order: my upper planes go up and fill the lower halo of peer_hi, whose first receive from me is its recv_lo, ...
@@ -45,11 +45,11 @@ struct RcclComm : Comm {
         if (rc) { ctx().err = first; return rc; }
         return rce;
     }
-    int allgather(void *buf, size_t bytes) override {
+    int do_allgather(void *buf, size_t bytes) override {
         return chk(ncclAllGather((const char *)buf + (size_t)rank * bytes, buf, bytes, ncclChar, nc, ctx().stream), "allgather");
     }
-    int group_begin() override { return chk(ncclGroupStart(), "groupStart"); }   // NCCL groups nest
-    int group_end() override { return chk(ncclGroupEnd(), "groupEnd"); }
+    int do_group_begin() override { return chk(ncclGroupStart(), "groupStart"); }   // NCCL groups nest
+    int do_group_end() override { return chk(ncclGroupEnd(), "groupEnd"); }
 };
 
 // Host-callback twin (tests: 2+ ranks sharing one GPU, transport = torch.distributed gloo).  Every operation
@@ -64,7 +64,7 @@ struct HostComm : Comm {
         cap = b * 2;
         return (int)hipHostMalloc((void **)&pin, cap, hipHostMallocDefault);
     }
-    int allreduce(double *dev, int n, int op) override {
+    int do_allreduce(double *dev, int n, int op) override {
         double v[8];
         WL_HIP(hipMemcpyAsync(v, dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx().stream));
         WL_HIP(hipStreamSynchronize(ctx().stream));
@@ -73,7 +73,7 @@ struct HostComm : Comm {
         WL_HIP(hipStreamSynchronize(ctx().stream));
         return 0;
     }
-    int sendrecv(const void *slo, void *rlo, const void *shi, void *rhi, size_t bytes, int plo, int phi) override {
+    int do_sendrecv(const void *slo, void *rlo, const void *shi, void *rhi, size_t bytes, int plo, int phi) override {
         WL_TRY(need(4 * bytes));
         char *hs_lo = pin, *hr_lo = pin + bytes, *hs_hi = pin + 2 * bytes, *hr_hi = pin + 3 * bytes;
         if (slo) WL_HIP(hipMemcpyAsync(hs_lo, slo, bytes, hipMemcpyDeviceToHost, ctx().stream));
@@ -86,7 +86,7 @@ struct HostComm : Comm {
         WL_HIP(hipStreamSynchronize(ctx().stream));
         return 0;
     }
-    int allgather(void *buf, size_t bytes) override {
+    int do_allgather(void *buf, size_t bytes) override {
         const size_t tot = bytes * (size_t)size;
         WL_TRY(need(tot));
         WL_HIP(hipMemcpyAsync(pin + (size_t)rank * bytes, (char *)buf + (size_t)rank * bytes, bytes, hipMemcpyDeviceToHost, ctx().stream));
@@ -204,6 +204,8 @@ struct wl_mg {
     Scratch sc;
     std::vector<void *> rowc;            // per level: row constants of L and iD (k_lrow), RC_N values per (j,k) row; D==3 only
     unsigned char *dirty = nullptr;      // level-0 row flags of wl_mg_update_changed
+    bool log_on = false;                 // wl_mg_log: record {n, Linf, L2} per solver iteration
+    std::vector<double> log;
     int alloc_rowc() {
         const size_t es = t == WL_F32 ? 4 : 8;
         rowc.assign(nlev, nullptr);
@@ -236,6 +238,7 @@ struct wl_flow {
     unsigned char *touched = nullptr, *prev = nullptr;
     unsigned char *changed = nullptr;   // rows whose coefficient arrays the last native measure! rewrote (touched now or before)
     bool changed_valid = false;
+    bool changed_pending = false;       // `changed` holds rows no update!(pois) has consumed yet: the next measure! ORs into it
     bool prev_valid = false;            // `prev` describes the arrays' current content (else: rewrite every row)
     long nband = -1;                    // result of the last wl_measure_rows (-1: none pending)
 };
@@ -321,10 +324,26 @@ template <class T, int D> static int mg_vcycle(wl_mg *m, int l, int *pcg_np = nu
 // solver!  src/MultiLevelPoisson.jl:87-99 (nlev>1) / src/Poisson.jl:162-172 (nlev==1).
 // One host synchronisation per iteration: the r2 < tol test (:95).
 // divu / gu: the right-hand side is div(u) of this velocity field, evaluated inside residual! (project!, single device)
+// L∞(p) = maximum(abs, p.r)  src/Poisson.jl:147 -> st->out[1]
+template <class T, int D> static int mg_Linf(wl_mg *m, int l) {
+    LevelT<T> p = lvl<T>(m, l);
+    const T *r = p.r;
+    return op_reduce<T, D>(p.g, WL_K_DOT, RED_MAX, 0.0, [=] __device__(long I) { const double v = (double)r[I]; return v < 0 ? -v : v; },
+                           m->sc.partials, m->sc.st, 1);
+}
+// one row of the reference's solver log: `@log ", $n, $(L∞(p)), $r₂\n"` (Poisson.jl:164,167; MultiLevelPoisson.jl:90,94)
+template <class T, int D> static int mg_log_row(wl_mg *m, int n, bool have_r2) {
+    if (!have_r2) WL_TRY((op_L2<T, D>(lvl<T>(m, 0), m->sc.partials, m->sc.st, false)));
+    WL_TRY((mg_Linf<T, D>(m, 0)));
+    WL_TRY(m->sc.fetch());
+    m->log.push_back((double)n); m->log.push_back(m->sc.hst->out[1]); m->log.push_back(m->sc.hst->r2);
+    return 0;
+}
 template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, int *n_iter, const T *divu = nullptr, const G *gu = nullptr) {
     LevelT<T> p = lvl<T>(m, 0);
     WL_TRY((op_residual<T, D>(p, m->permask, m->sc.partials, m->sc.st, divu, gu)));
     int n = 0;
+    if (m->log_on) WL_TRY((mg_log_row<T, D>(m, 0, false)));
     while (n < itmx) {
         int pre = -1;
         if (m->nlev > 1) WL_TRY((mg_vcycle<T, D>(m, 0, &pre)));
@@ -332,7 +351,9 @@ template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, in
         WL_TRY((op_L2<T, D>(p, m->sc.partials, m->sc.st, true)));
         WL_TRY(m->sc.fetch());
         ++n;
-        if (m->sc.hst->r2 < tol) break;
+        const double r2 = m->sc.hst->r2;
+        if (m->log_on) WL_TRY((mg_log_row<T, D>(m, n, true)));
+        if (r2 < tol) break;
     }
     WL_TRY((op_bc_per<T, D>(p.g, p.x, m->permask)));
     if (n_iter) *n_iter = n;
@@ -368,7 +389,8 @@ template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double d
     } else {
         if (exchange_u) WL_TRY((halo_exchange<T>(g, (T *)a->d.u, D, 1)));
         // single device, 3-D vector kernels: z = div(u) is formed inside residual! (wl_set_option(22)); p.z stays unwritten
-        fused_div = D == 3 && !g.dist && ctx().opt[22] && ctx().opt[5] && stencil7_ok<T>(g) && stencil7_ok<T>(p.g) && b->permask == 0 &&
+        // (rowvec_fits: a plane's workgroups fit the partial buffer -- the launch below cannot be rejected for its size)
+        fused_div = D == 3 && !g.dist && ctx().opt[22] && ctx().opt[5] && stencil7_ok<T>(g) && stencil7_ok<T>(p.g) && rowvec_fits<T>(p.g) && b->permask == 0 &&
                     g.s[1] == p.g.s[1] && g.s[2] == p.g.s[2] && g.n[0] == p.g.n[0];
         if (!fused_div) WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u)));
         if (!head_done) WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
@@ -665,9 +687,10 @@ template <class T, int D> static int measure_fill(wl_flow *a, const wl_body_desc
                        (const unsigned char *)a->touched, a->rowbuf, a->d.perdir_mask);
     WL_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_rows_changed, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, ctx().stream, (const unsigned char *)a->touched,
-                       (const unsigned char *)a->prev, !a->prev_valid, a->changed, (long)nrows);
+                       (const unsigned char *)a->prev, !a->prev_valid, a->changed_valid && a->changed_pending, a->changed, (long)nrows);
     WL_HIP(hipGetLastError());
     a->changed_valid = true;
+    a->changed_pending = true;
     WL_HIP(hipMemcpyAsync(a->prev, a->touched, nrows, hipMemcpyDeviceToDevice, ctx().stream));
     WL_TRY(flow_compact_busy(a, g, D));
     a->prev_valid = true;
@@ -938,17 +961,20 @@ int wl_mg_destroy(wl_mg *m) {
     if (!m || level < 0 || level >= m->nlev) return fail(WL_E_ARG, "bad level", __FILE__, __LINE__)
 
 int wl_mg_update(wl_mg *m) { WL_MG_DISPATCH((mg_update<T, DD>(m))); }
-int wl_mg_update_changed(wl_mg *m, const wl_flow *a) {
+int wl_mg_update_changed(wl_mg *m, wl_flow *a) {
     if (!m || !a) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);
     const wl_grid &gm = m->lev[0].g, &gf = a->d.g;
+    // a periodic z across slabs (ring): the ghost plane's source row lives on another rank -> full update
+    const bool zper = (m->permask >> 2) & 1, yper = (m->permask >> 1) & 1;
     const bool usable = a->changed_valid && a->changed && m->D == 3 && gf.D == 3 && gm.n[0] == gf.n[0] && gm.n[1] == gf.n[1] &&
-                        gm.n[2] == gf.n[2] && m->lev[0].L == a->d.mu0 && !m->rowc.empty() && m->rowc[0];
+                        gm.n[2] == gf.n[2] && m->lev[0].L == a->d.mu0 && !m->rowc.empty() && m->rowc[0] && !(zper && gm.nzg > 0);
+    a->changed_pending = false;   // consumed (by the partial or by the full update below)
     if (!usable) return wl_mg_update(m);
     const long nrows = (long)gm.n[1] * gm.n[2];
     if (!m->dirty) WL_HIP(hipMalloc((void **)&m->dirty, (size_t)nrows));
     // D, iD and the row constants of row (j,k) read L of the rows (j,k), (j+1,k), (j,k+1)
     hipLaunchKernelGGL(k_rows_dirty, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, ctx().stream, (const unsigned char *)a->changed,
-                       m->dirty, gm.n[1], gm.n[2]);
+                       m->dirty, gm.n[1], gm.n[2], (int)yper, (int)zper);
     WL_HIP(hipGetLastError());
     const unsigned char *dirty = m->dirty;
     WL_MG_DISPATCH((mg_update<T, DD>(m, dirty)));
@@ -1004,6 +1030,30 @@ int wl_mg_L2(wl_mg *m, int level, double *out) {
     *out = m->sc.hst->r2;
     return 0;
 }
+int wl_mg_Linf(wl_mg *m, int level, double *out) {
+    WL_LEVEL_OK();
+    if (!out) return fail(WL_E_ARG, "wl_mg_Linf: null output", __FILE__, __LINE__);
+    int rc = [&]() -> int { WL_MG_DISPATCH((mg_Linf<T, DD>(m, level))); }();
+    if (rc) return rc;
+    WL_TRY(m->sc.fetch());
+    *out = m->sc.hst->out[1];
+    return 0;
+}
+int wl_mg_log(wl_mg *m, int on) {
+    if (!m) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);
+    m->log_on = on != 0;
+    if (!on) m->log.clear();
+    return 0;
+}
+int wl_mg_log_read(wl_mg *m, double *rows, int cap, int *n) {
+    if (!m || !n || (cap > 0 && !rows)) return fail(WL_E_ARG, "wl_mg_log_read: null argument", __FILE__, __LINE__);
+    const int have = (int)(m->log.size() / 3);
+    const int take = have < cap ? have : (cap > 0 ? cap : 0);
+    for (int q = 0; q < 3 * take; ++q) rows[q] = m->log[q];
+    *n = have;
+    m->log.clear();
+    return 0;
+}
 int wl_mg_vcycle(wl_mg *m, int level) {
     if (!m || level < 0 || level + 1 >= m->nlev) return fail(WL_E_ARG, "bad level", __FILE__, __LINE__);
     WL_MG_DISPATCH((mg_vcycle<T, DD>(m, level)));
@@ -1045,6 +1095,7 @@ int wl_flow_destroy(wl_flow *a) {
 int wl_flow_update(wl_flow *a) {
     if (!a) return fail(WL_E_ARG, "null handle", __FILE__, __LINE__);
     a->changed_valid = false;   // the arrays were rewritten by the caller: nothing is known about which rows changed
+    a->changed_pending = false;
     WL_DISPATCH(a->t, a->d.g.D, (flow_update<T, DD>(a)));
 }
 int wl_measure_rows(wl_flow *a, const wl_body_desc *body, double eps, int64_t *nband) {
@@ -1165,6 +1216,12 @@ int wl_prof_reset(void) {
     for (int k = 0; k < WL_K_COUNT; ++k) { c.launches[k] = 0; c.cells[k] = 0; }
     for (auto &e : c.evts) { c.pool.push_back(e.a); c.pool.push_back(e.b); }
     c.evts.clear();
+    if (c.comm) for (int q = 0; q < 6; ++q) c.comm->cnt[q] = 0;
+    return 0;
+}
+int wl_prof_comm(int64_t out[6]) {
+    if (!out) return fail(WL_E_ARG, "wl_prof_comm: null output", __FILE__, __LINE__);
+    for (int q = 0; q < 6; ++q) out[q] = ctx().comm ? ctx().comm->cnt[q] : 0;
     return 0;
 }
 int wl_prof_counts(int kclass, int64_t *launches, int64_t *cells) {

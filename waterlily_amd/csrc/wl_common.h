@@ -31,13 +31,28 @@ struct TimedEvt { hipEvent_t a, b; int64_t cells; };
 // operations are enqueued on ctx().stream (RCCL) or staged through pinned host memory (host-callback twin).
 struct Comm {
     int rank = 0, size = 1;
+    // collectives issued since the last wl_prof_reset (wl_prof_comm): all-reduces, exchange batches, send/recv pairs,
+    // all-gathers, halo bytes sent, all-gather bytes contributed
+    int64_t cnt[6] = {0, 0, 0, 0, 0, 0};
+    int depth = 0;   // open group_begin()s
     virtual ~Comm() {}
-    virtual int allreduce(double *dev, int n, int op) = 0;                       // op: 0 sum, 1 max; in place
-    virtual int sendrecv(const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi, size_t bytes, int peer_lo,
-                         int peer_hi) = 0;
-    virtual int allgather(void *buf, size_t bytes_per_rank) = 0;                  // in place, rank r at r*bytes
-    virtual int group_begin() { return 0; }   // several sendrecv calls issued as ONE batch (one latency, not one each)
-    virtual int group_end() { return 0; }
+    int allreduce(double *dev, int n, int op) { cnt[0] += 1; return do_allreduce(dev, n, op); }   // op: 0 sum, 1 max; in place
+    int sendrecv(const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi, size_t bytes, int peer_lo, int peer_hi) {
+        if (depth == 0) cnt[1] += 1;
+        cnt[2] += (send_lo ? 1 : 0) + (send_hi ? 1 : 0);
+        cnt[4] += (int64_t)bytes * ((send_lo ? 1 : 0) + (send_hi ? 1 : 0));
+        return do_sendrecv(send_lo, recv_lo, send_hi, recv_hi, bytes, peer_lo, peer_hi);
+    }
+    int allgather(void *buf, size_t bytes_per_rank) { cnt[3] += 1; cnt[5] += (int64_t)bytes_per_rank; return do_allgather(buf, bytes_per_rank); }   // in place, rank r at r*bytes
+    // several sendrecv calls issued as ONE batch (one latency, not one each)
+    int group_begin() { if (depth++ == 0) cnt[1] += 1; return do_group_begin(); }
+    int group_end() { --depth; return do_group_end(); }
+    virtual int do_allreduce(double *dev, int n, int op) = 0;
+    virtual int do_sendrecv(const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi, size_t bytes, int peer_lo,
+                            int peer_hi) = 0;
+    virtual int do_allgather(void *buf, size_t bytes_per_rank) = 0;
+    virtual int do_group_begin() { return 0; }
+    virtual int do_group_end() { return 0; }
 };
 
 struct Ctx {

@@ -274,20 +274,26 @@ __global__ __launch_bounds__(256) void k_rowflags_touched(G g, const unsigned ch
     flags[row] = fre ? 1 : 0;
 }
 
-// rows whose coefficient arrays this measure! rewrote: touched now or at the previous measure! (all of them the first time)
-__global__ __launch_bounds__(256) static void k_rows_changed(const unsigned char *touched, const unsigned char *prev, bool all,
+// rows whose coefficient arrays this measure! rewrote: touched now or at the previous measure! (all of them the first time).
+// keep: an earlier measure!'s flags have not been consumed by update!(pois) yet (two measure! calls in a row): OR into them.
+__global__ __launch_bounds__(256) static void k_rows_changed(const unsigned char *touched, const unsigned char *prev, bool all, bool keep,
                                                             unsigned char *changed, long nrows) {
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
-    if (r < nrows) changed[r] = (all || touched[r] || prev[r]) ? 1 : 0;
+    if (r < nrows) changed[r] = (all || touched[r] || prev[r] || (keep && changed[r])) ? 1 : 0;
 }
-// level-0 rows whose D / iD / row constants read a changed row of L: the row itself and its lower y and z neighbours
-__global__ __launch_bounds__(256) static void k_rows_dirty(const unsigned char *changed, unsigned char *dirty, int n1, int n2) {
+// level-0 rows whose D / iD / row constants read a changed row of L: the row itself and its lower y and z neighbours.
+// Periodic y / z (single device): the ghost row above the last interior row is the periodic copy of the FIRST interior row
+// (BC!(mu0,0,perdir)), which never carries a flag of its own, so the last interior row also looks at the first one.
+__global__ __launch_bounds__(256) static void k_rows_dirty(const unsigned char *changed, unsigned char *dirty, int n1, int n2, int yper,
+                                                          int zper) {
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
     if (r >= (long)n1 * n2) return;
     const int j = (int)(r % n1), k = (int)(r / n1);
     bool d = changed[r] != 0;
     if (j + 1 < n1) d = d || changed[r + 1];
     if (k + 1 < n2) d = d || changed[r + n1];
+    if (yper && j == n1 - 2) d = d || changed[1 + (long)n1 * k];
+    if (zper && k == n2 - 2) d = d || changed[j + (long)n1 * 1];
     dirty[r] = d ? 1 : 0;
 }
 

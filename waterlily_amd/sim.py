@@ -102,24 +102,25 @@ _ARENA = {"buf": None, "pos": 0, "round": 1, "skew": 0}
 
 
 def set_arena(nbytes: int, device, round_to: int = 1 << 21, skew: int = 0) -> None:
-    """Carve every field allocated from now on out of one `nbytes` buffer: field k starts at the next multiple of
-    `round_to` after field k-1, plus `skew` bytes.  nbytes = 0 switches back to one torch allocation per field."""
+    """Carve every field allocated from now on out of one NEW `nbytes` buffer: field k starts at the next multiple of
+    `round_to` after field k-1, plus `skew` bytes.  nbytes = 0 switches back to one torch allocation per field.
+    (A fresh buffer per call: fields of earlier Simulations keep the previous buffer alive and are never overlapped.)"""
     if nbytes == 0:
         _ARENA.update(buf=None, pos=0)
         return
-    if _ARENA["buf"] is None or _ARENA["buf"].numel() < nbytes:
-        _ARENA["buf"] = None
-        _ARENA["buf"] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    _ARENA["buf"] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     _ARENA.update(pos=0, round=round_to, skew=skew)
 
 
 def _arena_take(nelem: int, dtype, device, fill: float) -> torch.Tensor:
     a = _ARENA
     item = torch.empty((), dtype=dtype).element_size()
-    if a["buf"] is None or a["pos"] + nelem * item + a["round"] + a["skew"] > a["buf"].numel():
+    if a["buf"] is None:
         return torch.full((nelem,), fill, dtype=dtype, device=device)
     start = -(-a["pos"] // a["round"]) * a["round"] + (a["skew"] if a["pos"] else 0)
     start = -(-start // 256) * 256
+    if start + nelem * item > a["buf"].numel():          # does not fit any more: an allocation of its own
+        return torch.full((nelem,), fill, dtype=dtype, device=device)
     a["pos"] = start + nelem * item
     out = a["buf"][start:start + nelem * item].view(dtype)
     out.fill_(fill)
@@ -560,6 +561,42 @@ def L2p(p, level=0) -> float:
     out = C.c_double()
     check(_lib.lib().wl_mg_L2(p._h, level, C.byref(out)))
     return out.value
+
+
+def Linf(p, level=0) -> float:
+    """Poisson.jl:147"""
+    out = C.c_double()
+    check(_lib.lib().wl_mg_Linf(p._h, level, C.byref(out)))
+    return out.value
+
+
+def solver_log(p, on=True) -> None:
+    """Switch the reference's pressure-solver log (`@log`, util.jl:4-24; Poisson.jl:164,167; MultiLevelPoisson.jl:90,94)
+    on or off for this hierarchy; read_solver_log returns the rows (n, L∞, L₂) recorded since the last read."""
+    check(_lib.lib().wl_mg_log(p._h, int(bool(on))))
+
+
+def read_solver_log(p, cap=4096) -> np.ndarray:
+    rows = (C.c_double * (3 * cap))()
+    n = C.c_int()
+    check(_lib.lib().wl_mg_log_read(p._h, rows, cap, C.byref(n)))
+    return np.array(rows[:3 * min(n.value, cap)], dtype=np.float64).reshape(-1, 3)
+
+
+def format_solver_log(rows, prefix="") -> str:
+    """the text WaterLily.logger writes: header "p/c, iter, r∞, r₂" (util.jl:23), then `prefix` ("p" / "c", Flow.jl:158,165)
+    in front of the n = 0 row of each solve"""
+    out = []
+    for n, rinf, r2 in rows:
+        out.append(f"{prefix if n == 0 else ''}, {int(n)}, {rinf}, {r2}\n")
+    return "".join(out)
+
+
+def comm_counts() -> dict:
+    """collectives this rank issued since the last wl_prof_reset (include/wlhip.h: wl_prof_comm)"""
+    v = (C.c_int64 * 6)()
+    check(_lib.lib().wl_prof_comm(v))
+    return dict(zip(("allreduce", "exchanges", "sendrecv_pairs", "allgather", "halo_bytes", "allgather_bytes"), (int(x) for x in v)))
 
 
 def Vcycle(ml: MultiLevelPoisson, l=0):
