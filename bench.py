@@ -263,6 +263,8 @@ def main():
         except Exception:
             traffic_db = {}
 
+    tkey = f"{m}^3/{args.dtype}" + ("" if args.body == "sphere" else "/" + args.body)   # case key of profiles/traffic.json
+
     def kernel_record(nm, launches, cells, total_ms):
         """bytes / rates of one kernel class from its launch count, summed cells and summed duration"""
         if not launches or total_ms <= 0:
@@ -275,12 +277,14 @@ def main():
         rate = need_b / (avg_ms * 1e-3) / 1e9
         drate = dense_b / (avg_ms * 1e-3) / 1e9
         rec = {"bound": "hbm", "kernel": nm, "achieved": rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate / HBM_PEAK_GBS,
-               "traffic": traffic_db.get(f"{nm}@{m}^3/{args.dtype}"), "launches": launches, "avg_launch_ms": avg_ms,
+               "traffic": traffic_db.get(f"{nm}@{tkey}"), "launches": launches, "avg_launch_ms": avg_ms,
                "algorithmic_bytes_per_launch": need_b,
                "dense": {"bytes_per_launch": dense_b, "GB/s": drate, "frac_of_peak": drate / HBM_PEAK_GBS,
                          "note": "SURVEY 8(d) per-cell figure of the reference operator; the fused kernel does not move these bytes"}}
         if rec["traffic"]:
             rec["traffic_GB/s"] = rec["traffic"] / (avg_ms * 1e-3) / 1e9
+            # a committed constant of an earlier rocprofv3 --pmc run of this command (tools/profile.sh), not measured by THIS run
+            rec["traffic_source"] = "profiles/" + str(traffic_db.get("_source", {}).get(tkey, "?")) + "_pmc_traffic_*"
         return rec
 
     roof = kernel_record(dominant, nl.value, nc.value, ms.value)

@@ -1,4 +1,4 @@
-# WaterLilyHIPNativeExt.jl -- reference-side binding of libwlhip.so (include/wlhip.h, ABI v4).
+# WaterLilyHIPNativeExt.jl -- reference-side binding of libwlhip.so (include/wlhip.h, ABI v5).
 #
 # NOT EXECUTED by this repository's tests: no Julia runtime exists in the build image or on the GPU box.  It is the
 # shim a WaterLily maintainer would add as a package extension (compare ext/WaterLilyAMDGPUExt.jl): a device array type
@@ -11,13 +11,14 @@
 module WaterLilyHIPNativeExt
 
 using WaterLily
-import WaterLily: Flow, Poisson, MultiLevelPoisson, AbstractPoisson, AbstractBody, mom_step!, conv_diff!, BDIM!, project!,
-                  BC!, exitBC!, perBC!, scale_u!, CFL, set_diag!, mult!, residual!, increment!, Jacobi!, pcg!, L₂,
-                  solver!, restrict!, prolongate!, restrictL!, Vcycle!, update!, measure!, apply!, pressure_force,
-                  viscous_force, pressure_moment, BCTuple, nds, loc, inside, time
+import WaterLily: Flow, Poisson, MultiLevelPoisson, AbstractPoisson, AbstractBody, Simulation, mom_step!, conv_diff!, BDIM!,
+                  project!, accelerate!, BC!, exitBC!, perBC!, scale_u!, CFL, set_diag!, mult!, residual!, increment!, Jacobi!,
+                  pcg!, L₂, L∞, solver!, restrict!, prolongate!, restrictL!, Vcycle!, update!, measure!, apply!, pressure_force,
+                  viscous_force, pressure_moment, BCTuple, nds, loc, inside, time, @log
 using StaticArrays
 import KernelAbstractions
 import LinearAlgebra
+using LinearAlgebra: I, inv
 
 const lib = get(ENV, "WLHIP_LIB", "libwlhip.so")
 
@@ -149,6 +150,15 @@ conv_diff!(r::HIPArray{T}, u::HIPArray{T}, Φ; ν=0.1, perdir=()) where T =     
 BDIM!(a::Flow{N,T,<:HIPArray}) where {N,T} =                                                    # src/Flow.jl:131-135
     chk(ccall((:wl_bdim, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
               Ptr{Cvoid}, Cdouble), dtype(T), grid(a.p), a.u.ptr, a.u⁰.ptr, a.f.ptr, a.V.ptr, a.μ₀.ptr, a.μ₁.ptr, a.Δt[end]))
+# accelerate!(r,dt,g,U)  src/Flow.jl:68-73: the host evaluates g(i,t) + dU_i/dt (closures, ForwardDiff), the library adds it
+accelerate!(r::HIPArray{T}, dt, g::Function, ::Tuple) where T = accel!(r, i -> g(i, sum(dt)))
+accelerate!(r::HIPArray{T}, dt, g::Nothing, U::Function) where T = accel!(r, i -> WaterLily.ForwardDiff.derivative(τ -> U(i, τ), sum(dt)))
+accelerate!(r::HIPArray{T}, dt, g::Function, U::Function) where T =
+    accel!(r, i -> g(i, sum(dt)) + WaterLily.ForwardDiff.derivative(τ -> U(i, τ), sum(dt)))
+accelerate!(r::HIPArray, dt, ::Nothing, ::Tuple) = nothing
+accel!(r::HIPArray{T}, f) where T =
+    chk(ccall((:wl_accelerate, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cdouble}), dtype(T), grid(r, ndims(r) - 1), r.ptr,
+              d3(ntuple(f, ndims(r) - 1))))
 scale_u!(a::Flow{N,T,<:HIPArray}, scale) where {N,T} =                                          # src/Flow.jl:170
     chk(ccall((:wl_scale_u, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Cdouble), dtype(T), grid(a.p), a.u.ptr, scale))
 function CFL(a::Flow{N,T,<:HIPArray}; Δt_max=10) where {N,T}                                    # src/Flow.jl:172-175
@@ -183,6 +193,10 @@ lvl(p, l) = p isa MultiLevelPoisson ? l - 1 : 0
 set_diag!(D::HIPArray{T}, iD::HIPArray{T}, L::HIPArray{T}) where T =                            # src/Poisson.jl:42-45
     chk(ccall((:wl_set_diag, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), dtype(T), grid(D), D.ptr, iD.ptr, L.ptr))
 update!(p::AbstractPoisson{T,<:HIPArray}) where T = chk(ccall((:wl_mg_update, lib), Cint, (Ptr{Cvoid},), handle(p)))
+# update!(pois) right after a NATIVE measure!(flow, ::ParametricBody): only the x-rows that measure! rewrote are revisited
+# on the finest level (same values; the library falls back to the full update by itself when that is not applicable)
+update!(p::AbstractPoisson{T,<:HIPArray}, a::Flow{N,T,<:HIPArray}) where {N,T} =
+    chk(ccall((:wl_mg_update_changed, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle(p), handle(a)))
 mult!(p::AbstractPoisson{T,<:HIPArray}, x::HIPArray) where T =                                  # src/Poisson.jl:62-68
     (chk(ccall((:wl_mg_mult, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), handle(p), 0, x.ptr)); p.z)
 residual!(p::Poisson{T,<:HIPArray}) where T = chk(ccall((:wl_mg_residual, lib), Cint, (Ptr{Cvoid}, Cint), handle(p), 0))
@@ -193,6 +207,13 @@ pcg!(p::Poisson{T,<:HIPArray}; it=6) where T =
 function L₂(p::Poisson{T,<:HIPArray}) where T                                                   # src/Poisson.jl:146
     o = Ref{Cdouble}(); chk(ccall((:wl_mg_L2, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), handle(p), 0, o)); T(o[])
 end
+function L∞(p::Poisson{T,<:HIPArray}) where T                                                   # src/Poisson.jl:147
+    o = Ref{Cdouble}(); chk(ccall((:wl_mg_Linf, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), handle(p), 0, o)); T(o[])
+end
+L₂(ml::MultiLevelPoisson{T,<:HIPArray}) where T = (o = Ref{Cdouble}();
+    chk(ccall((:wl_mg_L2, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), handle(ml), 0, o)); T(o[]))
+L∞(ml::MultiLevelPoisson{T,<:HIPArray}) where T = (o = Ref{Cdouble}();
+    chk(ccall((:wl_mg_Linf, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), handle(ml), 0, o)); T(o[]))
 Vcycle!(ml::MultiLevelPoisson{T,<:HIPArray}; l=1) where T = chk(ccall((:wl_mg_vcycle, lib), Cint, (Ptr{Cvoid}, Cint), handle(ml), l - 1))
 restrict!(a::HIPArray{T}, b::HIPArray{T}) where T =                                             # MultiLevelPoisson.jl:33
     chk(ccall((:wl_restrict, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ref{WlGrid}, Ptr{Cvoid}), dtype(T), grid(a), a.ptr, grid(b), b.ptr))
@@ -201,9 +222,22 @@ prolongate!(a::HIPArray{T}, b::HIPArray{T}) where T =                           
 restrictL!(a::HIPArray{T}, b::HIPArray{T}; perdir=()) where T =                                 # MultiLevelPoisson.jl:26-32
     chk(ccall((:wl_restrictL, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ref{WlGrid}, Ptr{Cvoid}, Cint),
               dtype(T), grid(a, ndims(a) - 1), a.ptr, grid(b, ndims(b) - 1), b.ptr, mask(perdir)))
+# The pressure-solver log (`WaterLily.logger`, src/util.jl:11-24): when the custom log level is enabled the library records
+# {n, L∞(p), L₂(p)} per iteration (wl_mg_log) and the rows are re-emitted through the reference's own @log macro, in the
+# reference's format (Poisson.jl:164,167; MultiLevelPoisson.jl:90,94)
+logging_on() = Base.CoreLogging.min_enabled_level(Base.CoreLogging.current_logger()) <= WaterLily._psolver
+function emit_log(h)
+    n = Ref{Cint}(); rows = zeros(Cdouble, 3 * 64)
+    chk(ccall((:wl_mg_log_read, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), h, rows, 64, n))
+    for q in 1:min(n[], 64)
+        @log ", $(Int(rows[3q-2])), $(rows[3q-1]), $(rows[3q])\n"
+    end
+end
 function solver!(p::AbstractPoisson{T,<:HIPArray}; tol=1e-4, itmx=(p isa MultiLevelPoisson ? 32 : 1e3)) where T
-    n = Ref{Cint}()                                                                             # MultiLevelPoisson.jl:87 / Poisson.jl:162
-    chk(ccall((:wl_mg_solve, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint, Ref{Cint}), handle(p), tol, Int(itmx), n))
+    n = Ref{Cint}(); h = handle(p); lg = logging_on()                                           # MultiLevelPoisson.jl:87 / Poisson.jl:162
+    chk(ccall((:wl_mg_log, lib), Cint, (Ptr{Cvoid}, Cint), h, lg))
+    chk(ccall((:wl_mg_solve, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint, Ref{Cint}), h, tol, Int(itmx), n))
+    lg && emit_log(h)
     push!(p.n, n[])
 end
 
@@ -223,8 +257,19 @@ function mom_step!(a::Flow{N,T,<:HIPArray}, b::AbstractPoisson) where {N,T}     
     U = d3(BCTuple(a.U, a.Δt, N))
     gp, gc = accel(a, @view(a.Δt[1:end-1])), accel(a, a.Δt)
     dt, n2 = Ref{Cdouble}(), zeros(Cint, 2)
+    hb = handle(b); lg = logging_on()
+    chk(ccall((:wl_mg_log, lib), Cint, (Ptr{Cvoid}, Cint), hb, lg))
     chk(ccall((:wl_mom_step, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
-              Ref{Cdouble}, Ptr{Cint}), handle(a), handle(b), a.Δt[end], U, gp, gc, dt, n2))
+              Ref{Cdouble}, Ptr{Cint}), handle(a), hb, a.Δt[end], U, gp, gc, dt, n2))
+    if lg   # the rows of the predictor's solve, then the corrector's: each starts with n = 0 (`@log "p"` / `@log "c"`, Flow.jl:158,165)
+        n = Ref{Cint}(); rows = zeros(Cdouble, 3 * 80)
+        chk(ccall((:wl_mg_log_read, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), hb, rows, 80, n))
+        tag = ("p", "c"); k = 0
+        for q in 1:min(n[], 80)
+            rows[3q-2] == 0 && (k += 1; @log tag[min(k, 2)])
+            @log ", $(Int(rows[3q-2])), $(rows[3q-1]), $(rows[3q])\n"
+        end
+    end
     append!(b.n, n2); push!(a.Δt, T(dt[]))
 end
 
@@ -234,6 +279,65 @@ function measure!(a::Flow{N,T,<:HIPArray}, body::AbstractBody; t=zero(T), ϵ=1) 
     measure!(h, body; t, ϵ)                                                                      # user closures + ForwardDiff on the host
     copyto!(a.μ₀, h.μ₀); copyto!(a.μ₁, h.μ₁); copyto!(a.V, h.V); copyto!(a.σ, h.σ)
     chk(ccall((:wl_flow_update, lib), Cint, (Ptr{Cvoid},), handle(a)))                          # rebuild the body-free row flags
+end
+# ---- parametric bodies: closed-form sdf family + affine map  =>  the whole measure! runs in the library (csrc/wl_measure.h)
+struct WlBody            # == wl_body_desc
+    family::Int32; identity_map::Int32; p::NTuple{8,Cdouble}
+    A::NTuple{9,Cdouble}; b::NTuple{3,Cdouble}; dA::NTuple{9,Cdouble}; db::NTuple{3,Cdouble}; Ainv::NTuple{9,Cdouble}
+end
+"""
+    ParametricBody(family, params; map=nothing)
+
+`family` ∈ (:sphere, :torus, :plate) with `params` = (c..., radius) | (c₁,c₂,c₃,R,r) | (a, thk) (include/wlhip.h);
+`map(t)` returns the affine map ξ = A x + b at time t as `(A, b)` (D×D matrix, D-vector).  Its time derivative comes from
+ForwardDiff, like `measure` gets `dot` (src/AutoBody.jl:128).  `sdf`/`measure` fall back to the equivalent `AutoBody`, so
+every generic code path (host `measure!`, `nds`, plotting) still works.
+"""
+struct ParametricBody{F} <: AbstractBody
+    family::Symbol; params::Vector{Float64}; map::F; auto::WaterLily.AutoBody
+end
+function ParametricBody(family::Symbol, params; map=nothing)
+    P = Float64.(collect(params))
+    sdf = family == :sphere ? (ξ, t) -> √sum(abs2, ξ .- P[1:length(ξ)]) - P[4] :
+          family == :torus  ? (ξ, t) -> √((ξ[1] - P[1])^2 + (√((ξ[2] - P[2])^2 + (ξ[3] - P[3])^2) - P[4])^2) - P[5] :
+                              (ξ, t) -> √sum(abs2, ξ .- SVector(clamp(ξ[1], -P[1], P[1]), ntuple(_ -> 0, length(ξ) - 1)...)) - P[2]
+    amap = map === nothing ? ((x, t) -> x) : ((x, t) -> ((A, b) = map(t); A * x + b))
+    ParametricBody(family, P, map, WaterLily.AutoBody(sdf, amap))
+end
+WaterLily.sdf(b::ParametricBody, x, t=0; kw...) = WaterLily.sdf(b.auto, x, t; kw...)
+WaterLily.measure(b::ParametricBody, x, t; kw...) = WaterLily.measure(b.auto, x, t; kw...)
+pad9(M, D) = ntuple(q -> ((r, c) = divrem(q - 1, 3); (r < D && c < D) ? Float64(M[r+1, c+1]) : 0.0), 9)   # row-major 3x3
+pad3(v, D) = ntuple(q -> q <= D ? Float64(v[q]) : 0.0, 3)
+function desc(body::ParametricBody, t, D)
+    fam = Int32(body.family == :sphere ? 0 : body.family == :torus ? 1 : 2)
+    p8 = ntuple(q -> q <= length(body.params) ? body.params[q] : 0.0, 8)
+    body.map === nothing && return WlBody(fam, 1, p8, pad9(I(D), D), pad3(zeros(D), D), pad9(zeros(D, D), D), pad3(zeros(D), D), pad9(I(D), D))
+    A, b = body.map(t)
+    dA = WaterLily.ForwardDiff.derivative(τ -> body.map(τ)[1], t); db = WaterLily.ForwardDiff.derivative(τ -> body.map(τ)[2], t)
+    WlBody(fam, 0, p8, pad9(A, D), pad3(b, D), pad9(dA, D), pad3(db, D), pad9(inv(A), D))
+end
+const BAND = IdDict{Any,Any}()       # flow => (t, band cells) of the last native measure!
+function measure!(a::Flow{N,T,<:HIPArray}, body::ParametricBody; t=zero(T), ϵ=1) where {N,T}     # src/Body.jl:31-53, all on the device
+    d = desc(body, t, N); nb = Ref{Int64}()
+    chk(ccall((:wl_measure_rows, lib), Cint, (Ptr{Cvoid}, Ref{WlBody}, Cdouble, Ref{Int64}), handle(a), d, ϵ, nb))
+    cand = HIPArray{Int64,1}((max(1, nb[]),))
+    chk(ccall((:wl_measure_fill, lib), Cint, (Ptr{Cvoid}, Ref{WlBody}, Cdouble, Ptr{Int64}), handle(a), d, ϵ, cand.ptr))
+    BAND[a] = (t, cand, nb[])
+    nothing
+end
+# measure!(sim, t)  src/WaterLily.jl:116-119: the native measure! is followed by the changed-rows update!(pois)
+function measure!(sim::Simulation{D,T,<:HIPArray}, t=sum(sim.flow.Δt)) where {D,T}
+    measure!(sim.flow, sim.body; t, ϵ=sim.ϵ)
+    sim.body isa ParametricBody ? update!(sim.pois, sim.flow) : update!(sim.pois)
+end
+# nds band of a parametric body (Metrics.jl:84-87): wl_body_nds on the band cells measure! listed; returns element offsets + vectors
+function band(p::HIPArray, body::ParametricBody, t)
+    D = ndims(p)
+    cells = Int64[LinearIndices(size(p))[I] - 1 for I ∈ inside(p)]     # (a maintainer would keep BAND[flow][2]: the |d|<2+ϵ cells)
+    cand = HIPArray(cells); v = HIPArray{Float64,1}((D * length(cells),))
+    chk(ccall((:wl_body_nds, lib), Cint, (Ref{WlGrid}, Ref{WlBody}, Ptr{Int64}, Int64, Ptr{Cdouble}), grid(p), desc(body, t, D),
+              cand.ptr, length(cells), v.ptr))
+    cand, v            # dense layout: the local column-major index IS the element offset wl_pforce expects
 end
 function band(p::HIPArray, body, t)                                                             # Metrics.jl:84-87 on the |d|<=1 band
     T = promote_type(Float64, eltype(p)); idx = Int64[]; v = Float64[]
@@ -259,5 +363,30 @@ function pressure_moment(x₀, p::HIPArray{T}, df, body, t=0, ::Type=Float64) wh
               dtype(T), grid(p), p.ptr, idx.ptr, v.ptr, length(idx), d3(x₀), o)); o[1:ndims(p)]
 end
 
-export HIPArray
+# ---------------------------------------------------------------------------------------------- multi-GPU bootstrap
+"""
+    init_slabs!(bcast)  ->  (rank, nranks) must already be known to the caller (MPI.jl, Distributed, ...)
+
+One process per GPU.  Rank 0 draws the RCCL unique id, `bcast(::Vector{UInt8})` hands the 128 bytes to every rank (e.g.
+`MPI.Bcast!(id, 0, comm)`), then every rank joins the communicator.  Afterwards a Flow / Poisson built on arrays whose
+`grid` carries the slab fields (`slab_grid`) runs the z-slab path: halo exchanges (ncclSend/ncclRecv on the library's comm
+stream), one ncclAllReduce per dot product, ncclAllGather at the hand-over to the replicated coarse levels.
+"""
+function init_slabs!(bcast, rank::Integer, nranks::Integer; device=rank)
+    chk(ccall((:wl_set_device, lib), Cint, (Cint,), device))
+    id = zeros(UInt8, 128)
+    rank == 0 && chk(ccall((:wl_comm_unique_id, lib), Cint, (Ptr{UInt8},), id))
+    bcast(id)
+    chk(ccall((:wl_comm_init_rccl, lib), Cint, (Ptr{UInt8}, Cint, Cint), id, rank, nranks))
+end
+finalize_slabs!() = chk(ccall((:wl_comm_finalize, lib), Cint, ()))
+"""wl_grid of rank `r`'s z-slab of an undecomposed array of extents `Ng` (ghosts included): nz/P interior planes + 2 halo
+planes per side (QUICK reads I-2δ..I+δ, src/Flow.jl:6); rank 0 owns the lower ghost plane, rank P-1 the upper one."""
+function slab_grid(Ng::NTuple{3,Int}, r, P; ring=false)
+    nzl = (Ng[3] - 2) ÷ P; n = (Ng[1], Ng[2], nzl + 4)
+    WlGrid(3, Int32.(n), (1, n[1], n[1] * n[2]), prod(n), Ng[3], r * nzl + 1 - 2, 2 - ((r == 0 && !ring) ? 1 : 0),
+           2 + nzl - 1 + ((r == P - 1 && !ring) ? 1 : 0), ring)
+end
+
+export HIPArray, ParametricBody, init_slabs!, finalize_slabs!, slab_grid
 end # module

@@ -8,7 +8,7 @@ Corrections, as /opt/skills/guides/MI355X_MICROARCH.md section "HBM" prescribes:
     kernels of this library whose byte counts are known exactly (pcg_direction: reads 2 arrays, writes 1;
     pcg_init: reads 2, writes 2): corrected reads land within +4..8 % of the known counts, writes are exact.
 
-usage: parse_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <tag e.g. 512^3/f32>
+usage: parse_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <case key e.g. 512^3/f32> [profile tag e.g. r03a]
 """
 import collections
 import csv
@@ -84,6 +84,7 @@ def collect(path, counter):
 
 def main():
     fpath, wpath, tag = sys.argv[1:4]
+    source = sys.argv[4] if len(sys.argv) > 4 else None
     rd, ri = collect(fpath, "FETCH_SIZE")
     rd = {k: 2.0 * v for k, v in rd.items()}
     wr, wi = collect(wpath, "WRITE_SIZE")
@@ -97,6 +98,10 @@ def main():
         n, lo, hi = ri.get(k, (0, 0, 0))
         spread = f"  [{n} launches, reads {2 * lo / 1e9:.2f}..{2 * hi / 1e9:.2f} GB]" if n else ""
         print(f"{k:14s} read(corrected) {rd.get(k, 0) / 1e9:7.3f} GB  write {wr.get(k, 0) / 1e9:7.3f} GB  total {tot / 1e9:7.3f} GB/launch{spread}")
+    if source:   # which profile the entries of this case came from (bench.py prints it next to `traffic`)
+        src = data.get("_source", {})
+        src[tag] = source
+        data["_source"] = src
     json.dump(data, open(tfile, "w"), indent=1, sort_keys=True)
 
 

@@ -1,4 +1,4 @@
-"""2-process gloo check of the host-callback collectives (no GPU, no HIP call): the ctypes callbacks that carry
+"""N-process gloo check of the host-callback collectives (no GPU, no HIP call): the ctypes callbacks that carry
 libwlhip's sendrecv / allreduce / allgather are invoked directly on host buffers."""
 import ctypes as C
 import json
@@ -34,11 +34,12 @@ def main():
         ok &= bool(np.all(r_lo == 100 + rank - 1))
     if hi:
         ok &= bool(np.all(r_hi == rank + 1))
-    # periodic ring with 2 ranks: both peers are the same rank; the prescribed op order must pair hi->lo and lo->hi
-    other = (rank + 1) % size
+    # periodic RING (z-periodic slabs): rank 0 and rank P-1 are neighbours.  With 2 ranks both peers are the same rank and
+    # the prescribed op order must pair hi->lo and lo->hi
+    plo, phi = (rank - 1) % size, (rank + 1) % size
     r_lo[:] = 0; r_hi[:] = 0
-    ok &= sr(None, p(s_lo), p(r_lo), p(s_hi), p(r_hi), nb, other, other) == 0
-    ok &= bool(np.all(r_lo == 100 + other)) and bool(np.all(r_hi == other))
+    ok &= sr(None, p(s_lo), p(r_lo), p(s_hi), p(r_hi), nb, plo, phi) == 0
+    ok &= bool(np.all(r_lo == 100 + plo)) and bool(np.all(r_hi == phi))
     # in-place allgather
     buf = np.zeros(size * 8, np.uint8)
     buf[rank * 8:(rank + 1) * 8] = rank + 1

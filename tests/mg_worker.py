@@ -23,7 +23,18 @@ from waterlily_amd.body import AutoBody, norm2  # noqa: E402
 
 def main():
     case = sys.argv[1] if len(sys.argv) > 1 else "sphere_f32"
-    if "rccl" in case:   # the production transport: one GPU per rank (world size 1 on a 1-GPU box)
+    if "rcclnet" in case:
+        # RCCL itself at N > 1 on a ONE-GPU box: every rank claims to sit on a different host (NCCL_HOSTID), so RCCL pairs the
+        # ranks over its socket transport (loopback) instead of refusing two ranks on one device.  Not an xGMI path, but the
+        # library's whole RCCL call pattern -- ncclCommInitRank, ncclCommSplit, grouped ncclSend/ncclRecv on the comm stream,
+        # ncclAllReduce / ncclAllGather on the compute stream -- really executes between two processes.
+        rk = os.environ.get("RANK", "0")
+        os.environ.update(NCCL_HOSTID=f"wl-test-host-{rk}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_P2P_DISABLE="1",
+                          NCCL_SHM_DISABLE="1", NCCL_NET_GDR_LEVEL="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+        wd.init_rccl()
+    elif "rccl" in case:   # the production transport: one GPU per rank (world size 1 on a 1-GPU box)
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
@@ -34,7 +45,7 @@ def main():
     rank, size = dist.get_rank(), dist.get_world_size()
     T = np.float64 if case.endswith("f64") else np.float32
     m = 32
-    dims = (m, m, m) if "long" not in case else (m, m, 2 * m)
+    dims = (m, m, m) if "long" not in case else (m, m, (4 if "vlong" in case else 2) * m)
     R, c = m / 8, m / 2 - 1
     if case.startswith("donut"):
         Rm, rm, cc = m / 4, m / 16, m / 2
@@ -57,8 +68,10 @@ def main():
         perdir = (1,)
     g = (lambda i, t: 0.05 * t if i == 0 else 0.0) if "accel" in case else None
     kw = dict(nu=nu, body=body, T=T, exitBC=("exit" in case), perdir=perdir, g=g)
-    if "rccl" in case:
+    if "rccl" in case and "rcclnet" not in case:
         kw["device"] = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+    if case.startswith("vtk"):
+        return vtk_roundtrip(rank, size, dims, L, kw)
     ref = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=None, **kw)
     slab = wd.Slab(rank, size, dims[2], ring=(2 in perdir))
     # "deep": keep every level a slab as long as the partition allows; default: replicate levels <= 2^21 cells
@@ -85,6 +98,52 @@ def main():
     out["overlapped"] = int(nov.value)
     out["force_ref"] = S.pressure_force(ref).tolist()
     out["force_slab"] = S.pressure_force(sim).tolist()
+    # collectives of ONE more step, counted by the library (wl_prof_comm), and the V-cycle counts of its two solves
+    _lib.check(_lib.lib().wl_prof_reset())
+    S.mom_step(sim.flow, sim.pois)
+    out["comm"] = S.comm_counts()
+    out["n_counted"] = sim.pois.n[-2:]
+    out["slab_nzl"] = [l.layout.slab.nzl if l.layout.slab is not None else None for l in sim.pois.levels]
+    wd.finalize()
+    if rank == 0:
+        print("RESULT " + json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
+def vtk_roundtrip(rank, size, dims, L, kw):
+    """VTK write -> restart on z-slabs (ext/WaterLilyWriteVTKExt.jl:57-66, ext/WaterLilyReadVTKExt.jl:28-45): the slabs
+    are gathered and rank 0 writes; on restart every rank loads the file and keeps its slab.  The restarted decomposed
+    simulation, and an undecomposed one restarted from the same file, must hold bitwise the fields that were written."""
+    from waterlily_amd import vtk
+    tmp = os.environ["WL_TMP"]
+    mk = lambda sl: S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=sl, **kw)
+    sim = mk(wd.Slab(rank, size, dims[2]))
+    for _ in range(2):
+        S.sim_step(sim, remeasure=False)
+    wr = vtk.vtkWriter(os.path.join(tmp, "slab_vtk"), dir=os.path.join(tmp, "SLAB_DIR"))
+    vtk.write(wr, sim)
+    vtk.close(wr)
+    dist.barrier()
+    pvd = os.path.join(tmp, "slab_vtk.pvd")
+    again, whole = mk(wd.Slab(rank, size, dims[2])), mk(None)
+    vtk.restart_sim(again, fname=pvd)
+    vtk.restart_sim(whole, fname=pvd)
+    out = {"rank": rank}
+    for k in ("u", "p"):
+        a, b, c = S.gather(getattr(sim.flow, k)), S.gather(getattr(again.flow, k)), S.to_host(getattr(whole.flow, k))
+        out["same_" + k] = bool(np.array_equal(a, b)) and bool(np.array_equal(a, c))
+    # the halo planes of the restarted slab are current too (the next conv_diff! reads two of them)
+    out["same_local_u"] = bool(torch.equal(sim.flow.u, again.flow.u))
+    out["dt"] = [sim.flow.dt[-1], again.flow.dt[-2], whole.flow.dt[-2]]
+    out["cfl"] = [again.flow.dt[-1], whole.flow.dt[-1]]
+    S.sim_step(again, remeasure=False)
+    S.sim_step(whole, remeasure=False)
+    a, b = S.gather(again.flow.u), S.to_host(whole.flow.u)
+    out["d_next"] = float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+    out["n_next"] = [again.pois.n[-2:], whole.pois.n[-2:]]
+    res = [None] * size
+    dist.all_gather_object(res, out["same_local_u"])
+    out["same_local_u"] = all(res)
     wd.finalize()
     if rank == 0:
         print("RESULT " + json.dumps(out), flush=True)

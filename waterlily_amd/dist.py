@@ -45,6 +45,47 @@ class Slab:
         return Slab(self.rank, self.size, self.nz // 2, self.ring)
 
 
+def divisible(shape) -> bool:
+    """MultiLevelPoisson.jl:36-37: the reference tests size(l.x), i.e. the extents INCLUDING the ghost layer"""
+    return all(n % 2 == 0 and n > 4 for n in shape)
+
+
+def plan_levels(Ng, slab: Optional[Slab], maxlevels: int = 10, replicate_cells: int = 1 << 21):
+    """The multigrid hierarchy of `MultiLevelPoisson` (restrictML, MultiLevelPoisson.jl:18-25,53-55) for arrays of
+    UNDECOMPOSED extents `Ng` (ghosts included): a list of (Ng_level, slab_or_None).  Multi-GPU: a level stays a z-slab
+    while every rank keeps >= 2 (even) planes AND the level has more than `replicate_cells` interior cells; from the
+    first level that fails either test on, every level is REPLICATED on all ranks (all-gather at the hand-over): no halo
+    exchange and no all-reduce per dot product on the latency-bound levels, and the hierarchy -- hence pois.n -- is
+    exactly the single-device one.  (Pure host arithmetic: tests/test_multi_gpu.py checks the 8-rank tables of C4 / C5.)"""
+    Ng = tuple(int(n) for n in Ng)
+    out = [(Ng, slab)]
+    while divisible(out[-1][0]) and len(out) <= maxlevels:
+        Na = tuple(1 + n // 2 for n in out[-1][0])
+        slab = slab.coarser() if slab is not None else None
+        if slab is not None and int(np.prod([n - 2 for n in Na])) <= replicate_cells:
+            slab = None
+        out.append((Na, slab))
+    return out
+
+
+def collectives_per_step(levels, vcycles, exitBC: bool = False, pcg_it: int = 6):
+    """How many collectives one `mom_step!` issues on a rank of a z-slab run, from the level plan and the V-cycle counts of
+    its two solves (`pois.n[-2:]`) -- the model DESIGN.md section 6 prices an 8-GPU step with, asserted against the
+    library's own counters (wl_prof_comm) in tests/test_multi_gpu.py.
+      all-reduces: CFL 1; exitBC! 1 (Flow.jl:160, once per step); per solve: residual! 1 + per V-cycle
+                   [(1 + 2*it) per slab level (pcg!: rho, then z.eps and r.z' / r.r per iteration) + 1 (L2)];
+      all-gathers: 1 per V-cycle (hand-over of the restricted residual to the replicated levels), if any level is replicated
+                   while level 0 is a slab.
+    Returns dict(allreduce=..., allgather=...)."""
+    nslab = sum(1 for _, s in levels if s is not None)
+    if nslab == 0:
+        return {"allreduce": 0, "allgather": 0}
+    handover = 1 if nslab < len(levels) else 0
+    nv = int(sum(vcycles))
+    ar = 1 + (1 if exitBC else 0) + len(vcycles) * 1 + nv * (nslab * (1 + 2 * pcg_it) + 1)
+    return {"allreduce": ar, "allgather": nv * handover}
+
+
 _state = {"kind": None, "rank": 0, "size": 1, "keep": None}
 
 

@@ -443,11 +443,6 @@ def _layout_of(x: torch.Tensor) -> Layout:
     return lay
 
 
-def _divisible(shape) -> bool:
-    """MultiLevelPoisson.jl:36-37"""
-    return all(n % 2 == 0 and n > 4 for n in shape)
-
-
 class _PoissonBase:
     def _create(self, levels, perdir):
         self.levels = levels
@@ -494,15 +489,9 @@ class MultiLevelPoisson(_PoissonBase):
         lay = _layout_of(x)
         lay.sc = L.stride(-1)
         levels = [_Level(lay, x, L, z, x.device)]
-        # restrictML, MultiLevelPoisson.jl:18-25,53-55.  Multi-GPU: a level stays a z-slab while every rank keeps
-        # >= 2 (even) planes; coarser levels are REPLICATED on every rank (all-gather at the hand-over), which
-        # keeps the hierarchy -- and hence the iteration counts -- identical to the single-device one.
-        slab = lay.slab
-        while _divisible(levels[-1].layout.Ng_global) and len(levels) <= maxlevels:
-            Na = tuple(1 + n // 2 for n in levels[-1].layout.Ng_global)
-            slab = slab.coarser() if slab is not None else None
-            if slab is not None and int(np.prod([n - 2 for n in Na])) <= replicate_cells:
-                slab = None
+        # restrictML, MultiLevelPoisson.jl:18-25,53-55; which levels stay z-slabs and which are replicated: dist.plan_levels
+        from .dist import plan_levels
+        for Na, slab in plan_levels(lay.Ng_global, lay.slab, maxlevels, replicate_cells)[1:]:
             la = Layout(Na, self.T, padded, slab)
             levels.append(_Level(la, la.alloc((), x.device), la.alloc((D,), x.device), la.alloc((), x.device), x.device))
         if len(levels) <= 2:
