@@ -84,8 +84,8 @@ def main():
     for _ in range(nsteps):
         S.sim_step(ref, remeasure="move" in case)
         S.sim_step(sim, remeasure="move" in case)
-    out["n_ref"], out["n_slab"] = ref.pois.n, sim.pois.n
-    out["dt_ref"], out["dt_slab"] = ref.flow.dt, sim.flow.dt
+    out["n_ref"], out["n_slab"] = list(ref.pois.n), list(sim.pois.n)
+    out["dt_ref"], out["dt_slab"] = list(ref.flow.dt), list(sim.flow.dt)
     for k in ("u", "p", "f"):
         a, b = S.gather(getattr(sim.flow, k)), S.to_host(getattr(ref.flow, k))
         if 2 in perdir and k == "f":

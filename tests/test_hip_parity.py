@@ -630,7 +630,9 @@ def test_periodic_deviation_at_the_reference_sizes(cfg):
     PERIODIC_DEV[cfg] = (du, ddt, len(so.flow.dt) - 1, nsame, len(so.pois.n))
     print(f"\nperiodic deviation {cfg}: steps={len(so.flow.dt) - 1} du={du:.3e} d(dt)={ddt:.3e} "
           f"V-cycle counts equal in {nsame}/{len(so.pois.n)} solves")
-    bound_u = {"TGV-64^2-f64": 2e-3, "TGV-64^2-f32": 2e-3, "channel-8^2-f64": 2e-3}[cfg]
+    # measured on MI355X (round 3): TGV f64 du = 1.9e-5, d(dt) = 1.5e-5; TGV f32 1.2e-4, 1.8e-5; channel: 0, 0 (no body, x
+    # periodic only: the stale ghost products vanish) -- bounds = 5x the measurement
+    bound_u = {"TGV-64^2-f64": 1e-4, "TGV-64^2-f32": 6e-4, "channel-8^2-f64": 1e-12}[cfg]
     assert du <= bound_u and ddt <= bound_u
     assert nsame >= len(so.pois.n) - 2          # (a solve at the tolerance's edge may take one V-cycle more or less)
 

@@ -1195,7 +1195,7 @@ int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx, c
 }
 
 int wl_set_option(int key, int value) {
-    if (key < 0 || key >= 24) return fail(WL_E_ARG, "wl_set_option: bad key", __FILE__, __LINE__);
+    if (key < 0 || key >= 32) return fail(WL_E_ARG, "wl_set_option: bad key", __FILE__, __LINE__);
     ctx().opt[key] = value;
     return 0;
 }

@@ -56,7 +56,7 @@ struct Comm {
 };
 
 struct Ctx {
-    int opt[24] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 1, 1, 1, 1};   // wl_set_option
+    int opt[32] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 1, 1, 1, 1, 1024, 0, 0, 0, 0, 0, 0, 0};   // wl_set_option
     Comm *comm = nullptr;
     hipStream_t stream = nullptr;
     std::string err;

@@ -1155,7 +1155,7 @@ int op_prolong_increment_fused(const LevelT<T> &p, const T *rin, const G &gc, co
                 T *e0 = p.eps;
                 const int tpp = (((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 3) / 4) + 7) / 8 * 8;
                 const int keep = ctx().opt[11];
-                if (tpp <= 1024) ctx().opt[11] = 1024 / tpp;   // few partials: pcg!'s first mult kernel may sum them itself
+                if (tpp <= ctx().opt[24]) ctx().opt[11] = ctx().opt[24] / tpp;   // few partials: pcg!'s first mult kernel may sum them itself
                 int np = 0;
                 const int rcv = launch_stencil7<T, 1>(WL_K_PROLONG, p.g, src, p.L, p.rowc, rin, p.x,
                     [=] __device__(long o, int i, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, const auto &rk, double *acc, const Pre &) {
@@ -1257,12 +1257,12 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     const bool distr = p.g.dist && ctx().comm && ctx().comm->size > 1;
     const bool infin = vec && xdef && zrec && R.count() > 0 && tpp_v > 0 &&
                        (distr ? ctx().opt[15] != 0
-                              : ((ctx().opt[15] == 2 || (ctx().opt[15] == 1 && R.count() <= (1L << 25))) && tpp_v <= 1024));
+                              : ((ctx().opt[15] == 2 || (ctx().opt[15] == 1 && R.count() <= (1L << 25))) && tpp_v <= ctx().opt[24]));
     struct CapGuard {   // the in-kernel sums want few partials: cap the number of z-chunks for the kernels of this call
         int o11, o12; bool on;
         CapGuard(bool on_, int cap) : o11(ctx().opt[11]), o12(ctx().opt[12]), on(on_) { if (on) { ctx().opt[11] = cap; ctx().opt[12] = cap; } }
         ~CapGuard() { if (on) { ctx().opt[11] = o11; ctx().opt[12] = o12; } }
-    } capguard(infin && !distr, (infin && !distr) ? std::max(1024 / std::max(tpp_v, 1), 1) : 0);
+    } capguard(infin && !distr, (infin && !distr) ? std::max(ctx().opt[24] / std::max(tpp_v, 1), 1) : 0);
     // what the consuming gate sums: the producer's partials, or (z-slabs) the one all-reduced value
     auto ready = [&](const double *&part, int &n) -> int {
         if (!distr) return 0;
