@@ -301,6 +301,7 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  *         0 = two launches of the per-cell gather
  * keys 16, 17: grid size of the 7-point / streaming vector kernels in units of 1024 workgroups (defaults 4 / 16: measured
  *         at 512^3, the streaming kernels gain 3-6 % from shorter z-chunks, the 7-point kernels do not)
+ * key 25: 1 = the shared-flux conv_diff! kernel uses 64x8 tiles for Float64 too (86.6 KB of LDS per workgroup), 0 = 64x4 (default)
  * key 24: budget of per-workgroup partials a pcg! kernel may sum itself (key 15): the grid of the kernels of such a call is
  *         capped at this many workgroups (default 1024, at most 16384)
  * keys 11, 12: > 0 = cap on the number of z-chunks of the 7-point / streaming vector kernels (measurement only) */

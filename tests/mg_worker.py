@@ -45,7 +45,7 @@ def main():
     rank, size = dist.get_rank(), dist.get_world_size()
     T = np.float64 if case.endswith("f64") else np.float32
     m = 32
-    dims = (m, m, m) if "long" not in case else (m, m, (4 if "vlong" in case else 2) * m)
+    dims = (m, m, m) if "long" not in case else ((2 * m, 2 * m, 4 * m) if "vlong" in case else (m, m, 2 * m))
     R, c = m / 8, m / 2 - 1
     if case.startswith("donut"):
         Rm, rm, cc = m / 4, m / 16, m / 2

@@ -96,7 +96,7 @@ def test_conv_diff_bit_exact(T, Ng, perdir):
 
 @pytest.mark.parametrize("T", TYPES)
 @pytest.mark.parametrize("Ng", [(200, 14, 12), (70, 22, 10), (130, 30, 7), (66, 10, 9), (66, 38, 8)])
-@pytest.mark.parametrize("shared", [1, 2, 0])
+@pytest.mark.parametrize("shared", [1, 2, 0, 3])
 def test_conv_diff_tile_paths_bit_exact(T, Ng, shared):
     """The LDS conv_diff kernels on shapes that exercise every tile kind: several x tiles per row (first / last with the
     domain's x-boundary faces, plain ones in between), partially filled last tiles, first / last tile rows and boundary
@@ -105,6 +105,7 @@ def test_conv_diff_tile_paths_bit_exact(T, Ng, shared):
     S.set_option(18, 1 if shared else 0)
     S.set_option(20, 0 if shared == 2 else 1)            # shared == 2: 64x4 tiles only (the default mixes 64x8 and 64x4)
     S.set_option(21, 0 if shared == 0 else 1)            # shared == 0: x-ghost planes by the per-cell gather as well
+    S.set_option(25, 1 if shared == 3 else 0)            # shared == 3: 64x8 tiles for Float64 too (86.6 KB of dynamic LDS)
     try:
         u = rnd(Ng + (3,), T, 8)
         r, Phi = O.zeros(Ng + (3,), T), O.zeros(Ng, T)
@@ -116,6 +117,7 @@ def test_conv_diff_tile_paths_bit_exact(T, Ng, shared):
         S.set_option(18, 1)
         S.set_option(20, 1)
         S.set_option(21, 1)
+        S.set_option(25, 0)
 
 
 @pytest.mark.parametrize("T", TYPES)

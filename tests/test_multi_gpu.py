@@ -167,8 +167,8 @@ def test_slabs_match_undecomposed(nproc, case):
     nslab = sum(1 for _, d in out["levels"] if d)
     assert (nslab >= 3 if "deep" in case else nslab == 1) and not out["levels"][-1][1]
     assert out["overlapped"] > 0          # stencil launches were split around exchanges on the comm stream
-    if "vlong" in case:                   # 32x32x128 on 4 ranks: 32, 16, 8, 4, 2 planes per rank, then the hand-over
-        assert out["slab_nzl"][:5] == [32, 16, 8, 4, 2] and out["slab_nzl"][5] is None
+    if "vlong" in case:                   # 64x64x128 on 4 ranks: 32, 16, 8, 4, 2 planes per rank, then the hand-over to 4^3
+        assert out["slab_nzl"] == [32, 16, 8, 4, 2, None]
     check(out, "f64" if case.endswith("f64") else "f32")
     check_collectives(out, exitBC="exit" in case)
 

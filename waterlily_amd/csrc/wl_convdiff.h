@@ -447,7 +447,9 @@ template <class T, bool FUSE, bool COPY, int BY>
 __global__ __launch_bounds__(CD_BX *BY) void k_convdiff3s(G g, T *__restrict__ r, const T *__restrict__ u, T nu, const T *u0, T *u0out,
                                                          const T *__restrict__ V, T dt, double a0, double a1, double a2, bool has_acc,
                                                          int ntx, int tpp, int nblk, int clen, int jbase, int klo, int khi, int ntile) {
-    __shared__ CdsShared<T, BY> S_;
+    // (dynamic LDS: CdsShared<double, 8> is 86.6 KB -- more than the 64 KB a static __shared__ object may take)
+    extern __shared__ __attribute__((aligned(16))) unsigned char cds_raw[];
+    CdsShared<T, BY> &S_ = *reinterpret_cast<CdsShared<T, BY> *>(cds_raw);
     const int b = blockIdx.x;
     const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);  // XCD-contiguous logical id
     const int ch = lb / tpp, pt = lb - ch * tpp;
@@ -507,7 +509,9 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
     // planes with interior z faces only, clipped to the owned planes
     int klo = g.zlo, khi = g.zhi;
     if (!g.zring) { klo = max(klo, 2 - g.kz0); khi = min(khi, g.nzg - 3 - g.kz0); }
-    const bool use8 = sizeof(T) == 4 && ctx().opt[20] != 0;
+    // Float64: 8-row tiles need 86.6 KB of LDS = ONE 512-thread workgroup (8 wavefronts) per CU where the 4-row tiles run
+    // three 256-thread workgroups (12 wavefronts); wl_set_option(25, 1) selects them (measured: see DESIGN.md section 5)
+    const bool use8 = (sizeof(T) == 4 && ctx().opt[20] != 0) || (sizeof(T) == 8 && ctx().opt[20] != 0 && ctx().opt[25] != 0);
     int thi_s = thi;
     if (use8 && ((thi_s - tlo + 1) & 1) && thi_s > tlo) --thi_s;   // 8-row tiles: an odd tile row goes to the shell
     const bool shared = ctx().opt[18] != 0 && thi_s >= tlo && khi >= klo;
@@ -524,8 +528,8 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
     // (3) interior planes, interior tile rows: shared-flux kernel; x-boundary tiles in a launch of their own (GENX)
     const int nty = thi - tlo + 1;
     const int nown = khi - klo + 1;
-    // 8-row tiles where the element type leaves room for them in LDS (Float32: 43 KB per workgroup), 4-row tiles for the
-    // rows that do not fill one (and for Float64)
+    // 8-row tiles (Float32: 43 KB of LDS per workgroup; Float64: 86.6 KB, optional), 4-row tiles for the rows that do not
+    // fill one
     auto launch = [&](auto BYc, int jbase, int ntr) -> int {   // ntr tile rows of BY rows starting at row jbase
         constexpr int BY = decltype(BYc)::value;
         if (ntr <= 0) return 0;
@@ -537,7 +541,16 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
         const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
         const int nblk = tpp * nchunk;
         Prof p(WL_K_CONVDIFF, (long)g.n[0] * (long)(ntr * BY) * nown);
-        hipLaunchKernelGGL((k_convdiff3s<T, FUSE, COPY, BY>), dim3(nblk), dim3(CD_BX * BY), 0, ctx().stream, g, r, u, (T)nu_, u0, u0out, V,
+        constexpr size_t lds = sizeof(CdsShared<T, BY>);
+        if (lds > 64 * 1024) {
+            static bool raised = false;   // (per instantiation)
+            if (!raised) {
+                WL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_convdiff3s<T, FUSE, COPY, BY>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                raised = true;
+            }
+        }
+        hipLaunchKernelGGL((k_convdiff3s<T, FUSE, COPY, BY>), dim3(nblk), dim3(CD_BX * BY), lds, ctx().stream, g, r, u, (T)nu_, u0, u0out, V,
                            (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen, jbase, klo, khi, ntile);
         return (int)hipGetLastError();
     };

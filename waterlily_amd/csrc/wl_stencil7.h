@@ -356,6 +356,10 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
         }
         Fly A, B;
         request(A, k0);
+        VA lzc[R];              // upper z-face coefficients of plane k-1 (rows that loaded L), see (3)
+        bool lzok[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) { lzc[q] = VA::splat((T)0); lzok[q] = false; }
 
         auto step = [&](int k, Fly &cur, Fly &nxt) {
             const long ok = col + sz * k;
@@ -385,7 +389,14 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
 #pragma unroll
                 for (int q = 0; q < R; ++q) ep[q] = src.xf(cur.own[q], RKT(cur.rk[q]), col + q * sy + sz * kn, i);
                 const VA ylo = src.xf(cur.hlo, RKT(cur.rkl), ok - sy, i), yhi = src.xf(cur.hhi, RKT(cur.rkh), ok + R * sy, i);
-                // (3) the stencil, row by row
+                // (3) the stencil, row by row.  In rows that load L, a face coefficient shared with the cell processed just before
+                // is loaded ONCE: the lower y face of row q is the upper y face of row q-1 (same iteration), the lower z face
+                // of plane k the upper z face of plane k-1 (kept from the previous iteration) -- 3 to 3.5 vector loads of L
+                // per row instead of 5 (the second read of Lz came one plane later, mostly from HBM again: bodies that cut
+                // many rows, e.g. the torus of C5, paid 0.7 of an array pass for it).  A coefficient-uniform neighbour has
+                // that face equal to its constant c, by the definition of uniform.
+                VA lyc;                 // upper y face of the previous row of this strip
+                bool lyok = false;
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
                     const long o = ok + q * sy;
@@ -396,9 +407,16 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
                         lx = VA::splat(rc.c); ly0 = lx; ly1 = lx; lz0 = lx; lz1 = lx;
                         if (i == 1) lx.v[0] = rc.lxf;
                         lxr = (i + V > nxi) ? rc.lxl : rc.c;
+                        if (!F) { lyc = ly1; lyok = true; lzc[q] = lz1; }
+                        lzok[q] = !F;   // (the all-uniform copy of the plane body keeps no vector state: a later general plane reloads)
                     } else {
-                        lx = VA::load(Lx + o); ly0 = VA::load(Ly + o); ly1 = VA::load(Ly + o + sy);
-                        lz0 = VA::load(Lz + o); lz1 = VA::load(Lz + o + sz);
+                        lx = VA::load(Lx + o);
+                        if (lyok) ly0 = lyc; else ly0 = VA::load(Ly + o);
+                        ly1 = VA::load(Ly + o + sy);
+                        if (lzok[q]) lz0 = lzc[q]; else lz0 = VA::load(Lz + o);
+                        lz1 = VA::load(Lz + o + sz);
+                        lyc = ly1; lyok = true;
+                        lzc[q] = lz1; lzok[q] = true;
                         lxr = lane_dn1(lx.v[0]);
                         if (last) lxr = Lx[o + V];
                     }
