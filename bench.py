@@ -239,7 +239,9 @@ def main():
     n0 = len(sim.pois.n)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
+        if it == args.steps - 1 and world > 1:
+            _lib.check(L.wl_prof_reset_comm())   # count the collectives of the last timed step only (host counters: no GPU work)
         S.sim_step(sim, remeasure=False)
     sync()
     elapsed = time.perf_counter() - t0
@@ -306,6 +308,9 @@ def main():
                                                      and args.dtype == "f32" and args.body == "sphere" else "" if world == 1 else
                                                      f", z-slabs over {world} GPUs"),
                    "transport": transport, "comm_ranks": cn.value,
+                   "scalar_allreduce": ("none" if world == 1 else ("mailbox(pinned host memory)" if wd.mailbox_active() else
+                                                                   ("ncclAllReduce" if args.comm == "rccl" else "host callbacks"))),
+                   "collectives_last_step": S.comm_counts() if world > 1 else None,
                    "vcycles_per_solve": vcycles[:6], "mean_vcycles_per_step": float(np.sum(vcycles)) / args.steps},
         "roofline": roof,
         "smoother": kernel_record("smooth", sm["launches"], sm["cells"], sm["ms"]) if sm else None,

@@ -83,6 +83,16 @@ typedef int (*wl_host_allreduce_fn)(void *user, double *vals, int n, int op);
 typedef int (*wl_host_allgather_fn)(void *user, void *buf, int64_t bytes);
 int wl_comm_init_host(int rank, int nranks, wl_host_sendrecv_fn sr, wl_host_allreduce_fn ar, wl_host_allgather_fn ag,
                       void *user);
+/* Mailbox all-reduce for the run's scalars (dot products, CFL maximum, force sums): after the communicator exists every rank
+ * of the NODE opens the same POSIX shared-memory object `shm_name` ("/name"); the one rank that passes create != 0 must
+ * have returned before the others call (the host orders it: create on rank 0, barrier, open elsewhere, barrier, then rank 0
+ * may shm_unlink the name).  From then on the library sums its scalars through that block of pinned host memory -- one
+ * system-scope store + one poll per peer, combined in rank order (bit-identical on every rank) -- instead of one RCCL
+ * all-reduce per value; halo planes and the coarse-level all-gather stay on RCCL.  Waits are bounded: a rank that gives up
+ * reports WL_E_STATE at the caller's next synchronising call.  Optional: without it scalars use ncclAllReduce. */
+int wl_comm_mailbox(const char *shm_name, int create);
+int wl_comm_mailbox_off(void);          /* back to the communicator's all-reduce (every rank must call it at the same point) */
+int wl_comm_mailbox_active(int *on);
 int wl_comm_finalize(void);
 int wl_comm_rank(int *rank, int *nranks);
 /* fill the halo planes of a (vector) field from the z-neighbours: `depth` planes each side, `ncomp` components */
@@ -301,6 +311,7 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  *         0 = two launches of the per-cell gather
  * keys 16, 17: grid size of the 7-point / streaming vector kernels in units of 1024 workgroups (defaults 4 / 16: measured
  *         at 512^3, the streaming kernels gain 3-6 % from shorter z-chunks, the 7-point kernels do not)
+ * key 26: bound of a mailbox all-reduce's wait for a peer, in thousands of polls (default 40000, about a minute)
  * key 25: 1 = the shared-flux conv_diff! kernel uses 64x8 tiles for Float64 too (86.6 KB of LDS per workgroup), 0 = 64x4 (default)
  * key 24: budget of per-workgroup partials a pcg! kernel may sum itself (key 15): the grid of the kernels of such a call is
  *         capped at this many workgroups (default 1024, at most 16384)
@@ -329,6 +340,7 @@ int wl_prof_overlapped(int64_t *count);
  * component and neighbour side), out[3] all-gathers, out[4] bytes this rank sent in halo exchanges, out[5] bytes it
  * contributed to all-gathers */
 int wl_prof_comm(int64_t out[6]);
+int wl_prof_reset_comm(void);           /* zero these six counters only (wl_prof_reset zeroes them too) */
 /* for the selected class: timed launches, their summed cells, summed milliseconds (synchronises) */
 int wl_prof_timed(int64_t *launches, int64_t *cells, double *ms);
 

@@ -72,6 +72,8 @@ def main():
         kw["device"] = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
     if case.startswith("vtk"):
         return vtk_roundtrip(rank, size, dims, L, kw)
+    if case.startswith("mboxtimeout"):
+        return mailbox_timeout(rank, size)
     ref = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=None, **kw)
     slab = wd.Slab(rank, size, dims[2], ring=(2 in perdir))
     # "deep": keep every level a slab as long as the partition allows; default: replicate levels <= 2^21 cells
@@ -102,11 +104,36 @@ def main():
     _lib.check(_lib.lib().wl_prof_reset())
     S.mom_step(sim.flow, sim.pois)
     out["comm"] = S.comm_counts()
+    out["mailbox"] = wd.mailbox_active()
     out["n_counted"] = sim.pois.n[-2:]
     out["slab_nzl"] = [l.layout.slab.nzl if l.layout.slab is not None else None for l in sim.pois.levels]
     wd.finalize()
     if rank == 0:
         print("RESULT " + json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
+def mailbox_timeout(rank, size):
+    """the mailbox all-reduce's waits are bounded: a rank whose peer never posts gives up, and the library reports it"""
+    import time
+    Lb = _lib.lib()
+    assert wd.mailbox_active()
+    v = (C.c_double * 1)(float(rank + 1))
+    _lib.check(Lb.wl_allreduce(v, 1, 0))                       # a healthy round first
+    ok_sum = v[0] == sum(range(1, size + 1))
+    S.set_option(26, 300)                                      # 300 000 polls: a fraction of a second
+    raised, msg = False, ""
+    if rank == 0:
+        try:
+            _lib.check(Lb.wl_allreduce(v, 1, 0))               # rank 1 never joins this one
+        except _lib.WlError as e:
+            raised, msg = True, str(e)
+    else:
+        time.sleep(4.0)
+    dist.barrier()
+    Lb.wl_comm_finalize()
+    if rank == 0:
+        print("RESULT " + json.dumps({"ok_sum": bool(ok_sum), "raised": raised, "msg": msg}), flush=True)
     dist.destroy_process_group()
 
 

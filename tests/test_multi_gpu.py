@@ -169,12 +169,22 @@ def test_slabs_match_undecomposed(nproc, case):
     assert out["overlapped"] > 0          # stencil launches were split around exchanges on the comm stream
     if "vlong" in case:                   # 64x64x128 on 4 ranks: 32, 16, 8, 4, 2 planes per rank, then the hand-over to 4^3
         assert out["slab_nzl"] == [32, 16, 8, 4, 2, None]
+    assert out["mailbox"]                 # scalars went through the mailbox all-reduce (the default once a communicator exists)
     check(out, "f64" if case.endswith("f64") else "f32")
     check_collectives(out, exitBC="exit" in case)
 
 
 @pytest.mark.gpu
-def test_rccl_two_ranks_on_one_gpu_over_sockets():
+def test_mailbox_allreduce_gives_up_on_a_missing_peer():
+    """the waits of the mailbox all-reduce are bounded (wl_set_option(26)): a healthy round sums correctly; when a peer never
+    posts, the waiting rank's kernel ends, and the library turns the flag into an error at its next synchronisation"""
+    out = run_workers("mg_worker.py", 2, "mboxtimeout_f32", timeout=120)
+    assert out["ok_sum"] and out["raised"] and "mailbox" in out["msg"], out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mailbox", ["1", "0"], ids=["mailbox-scalars", "ncclAllReduce-scalars"])
+def test_rccl_two_ranks_on_one_gpu_over_sockets(mailbox):
     """RCCL ITSELF at world size 2 on the one-GPU test box: the two ranks share the device but present themselves to RCCL
     as two hosts (NCCL_HOSTID), so the communicator pairs them over its socket transport.  Everything the library does
     with RCCL runs between two real processes -- ncclCommInitRank from a broadcast unique id, ncclCommSplit for the halo
@@ -182,12 +192,12 @@ def test_rccl_two_ranks_on_one_gpu_over_sockets():
     dot product, ncclAllGather at the hand-over to the replicated levels -- and must reproduce the undecomposed run.
     What it cannot show is xGMI bandwidth or latency.  If this RCCL build cannot bring up such a communicator at all
     (no usable loopback interface) the test is skipped with RCCL's message; a wrong result or a hang is a failure."""
-    out = run_workers("mg_worker.py", 2, "sphere_rcclnet_deep_f32", timeout=300, allow_fail=True, NCCL_DEBUG="WARN")
+    out = run_workers("mg_worker.py", 2, "sphere_rcclnet_deep_f32", timeout=300, allow_fail=True, NCCL_DEBUG="WARN", WL_MAILBOX=mailbox)
     if out.get("failed"):
         if "RESULT" not in out["tail"] and ("rccl" in out["tail"].lower() or "nccl" in out["tail"].lower()):
             pytest.skip("RCCL could not create a 2-rank communicator on one GPU: " + out["tail"][-600:])
         raise AssertionError(out["tail"])
-    assert out["overlapped"] > 0
+    assert out["overlapped"] > 0 and out["mailbox"] == (mailbox == "1")
     check(out, "f32")
     check_collectives(out)
 
@@ -197,8 +207,8 @@ def test_rccl_two_ranks_on_one_gpu_over_sockets():
 def test_slabs_match_without_overlap(nproc, case):
     """Same, with the halo exchanges issued in-stream (WL_OVERLAP=0) instead of on the comm stream with the stencil
     launches split into inner planes (concurrent with the transfer) and the two boundary planes (after it)."""
-    out = run_workers("mg_worker.py", nproc, case, WL_OVERLAP="0")
-    assert out["overlapped"] == 0
+    out = run_workers("mg_worker.py", nproc, case, WL_OVERLAP="0", WL_MAILBOX="0")
+    assert out["overlapped"] == 0 and not out["mailbox"]     # (and the scalars through the transport's own all-reduce)
     check(out, "f64" if case.endswith("f64") else "f32")
 
 

@@ -94,6 +94,9 @@ def lib() -> C.CDLL:
         "wl_comm_unique_id": (i, [vp]),
         "wl_comm_init_rccl": (i, [vp, i, i]),
         "wl_comm_init_host": (i, [i, i, SENDRECV_FN, ALLREDUCE_FN, ALLGATHER_FN, vp]),
+        "wl_comm_mailbox": (i, [C.c_char_p, i]),
+        "wl_comm_mailbox_off": (i, []),
+        "wl_comm_mailbox_active": (i, [ip]),
         "wl_comm_finalize": (i, []),
         "wl_comm_rank": (i, [ip, ip]),
         "wl_halo_exchange": (i, [i, gp, vp, i, i]),
@@ -150,6 +153,7 @@ def lib() -> C.CDLL:
         "wl_prof_overlapped": (i, [C.POINTER(i64)]),
         "wl_prof_counts": (i, [i, C.POINTER(i64), C.POINTER(i64)]),
         "wl_prof_comm": (i, [C.POINTER(i64)]),
+        "wl_prof_reset_comm": (i, []),
         "wl_prof_timed": (i, [C.POINTER(i64), C.POINTER(i64), dp]),
     }
     for name, (res, args) in sig.items():

@@ -2,6 +2,11 @@
 #include <cstdarg>
 #include <cstring>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <rccl/rccl.h>
 
 #include "wl_ops.h"
@@ -179,6 +184,8 @@ struct Scratch {
     int fetch() {
         WL_HIP(hipMemcpyAsync(hst, st, sizeof(State), hipMemcpyDeviceToHost, ctx().stream));
         WL_HIP(hipStreamSynchronize(ctx().stream));
+        if (ctx().mbox && *ctx().mbox->err_host)
+            return fail(WL_E_STATE, "mailbox all-reduce: gave up waiting for a peer rank (is every rank still running?)", __FILE__, __LINE__);
         return 0;
     }
 };
@@ -763,10 +770,67 @@ int wl_comm_init_host(int rank, int nranks, wl_host_sendrecv_fn sr, wl_host_allr
     ctx().comm = c;
     return 0;
 }
+static void mailbox_release() {
+    Mailbox *mb = ctx().mbox;
+    if (!mb) return;
+    if (mb->host) { (void)hipHostUnregister(mb->host); munmap(mb->host, mb->bytes); }
+    if (mb->err_host) (void)hipHostFree(mb->err_host);
+    delete mb;
+    ctx().mbox = nullptr;
+}
+// Mailbox all-reduce (wl_common.h: Mailbox).  `shm_name` ("/wlhip-...") names a POSIX shared-memory object every rank of the
+// node opens; the rank with create != 0 makes and sizes it first (the host orders the calls: create, barrier, open).
+int wl_comm_mailbox(const char *shm_name, int create) {
+    Comm *cm = ctx().comm;
+    if (!cm) return fail(WL_E_STATE, "wl_comm_mailbox: initialise the communicator first", __FILE__, __LINE__);
+    if (!shm_name || shm_name[0] != '/') return fail(WL_E_ARG, "wl_comm_mailbox: name must start with '/'", __FILE__, __LINE__);
+    if (cm->size > WL_MBOX_MAXRANKS) return fail(WL_E_ARG, "wl_comm_mailbox: too many ranks", __FILE__, __LINE__);
+    mailbox_release();
+    const size_t bytes = ((2 * (size_t)cm->size * sizeof(MboxSlot) + 4095) / 4096) * 4096;
+    const int fd = create ? shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600) : shm_open(shm_name, O_RDWR, 0600);
+    if (fd < 0) return fail(WL_E_STATE, "wl_comm_mailbox: shm_open failed", __FILE__, __LINE__);
+    if (create && ftruncate(fd, (off_t)bytes) != 0) { close(fd); return fail(WL_E_STATE, "wl_comm_mailbox: ftruncate failed", __FILE__, __LINE__); }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) { close(fd); return fail(WL_E_STATE, "wl_comm_mailbox: shared object too small", __FILE__, __LINE__); }
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);   // (fresh shared memory reads as zero: seq 0 = nothing posted)
+    close(fd);
+    if (p == MAP_FAILED) return fail(WL_E_STATE, "wl_comm_mailbox: mmap failed", __FILE__, __LINE__);
+    Mailbox *mb = new Mailbox();
+    mb->bytes = bytes;
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) { munmap(p, bytes); delete mb; return fail((int)e, "wl_comm_mailbox: hipHostRegister", __FILE__, __LINE__); }
+    mb->host = (MboxSlot *)p;
+    void *dp = nullptr;
+    e = hipHostGetDevicePointer(&dp, p, 0);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&mb->err_host, sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) { *mb->err_host = 0; e = hipHostGetDevicePointer((void **)&mb->err_dev, mb->err_host, 0); }
+    if (e != hipSuccess) {
+        (void)hipHostUnregister(p); munmap(p, bytes);
+        if (mb->err_host) (void)hipHostFree(mb->err_host);
+        delete mb;
+        return fail((int)e, "wl_comm_mailbox: device mapping", __FILE__, __LINE__);
+    }
+    mb->dev = (MboxSlot *)dp;
+    ctx().mbox = mb;
+    return 0;
+}
+int wl_comm_mailbox_off(void) {
+    if (ctx().mbox) {
+        (void)hipStreamSynchronize(ctx().stream);
+        mailbox_release();
+    }
+    return 0;
+}
+int wl_comm_mailbox_active(int *on) {
+    if (!on) return fail(WL_E_ARG, "null output", __FILE__, __LINE__);
+    *on = ctx().mbox != nullptr;
+    return 0;
+}
 int wl_comm_finalize(void) {
     if (ctx().comm) {
         (void)hipStreamSynchronize(ctx().stream);
         if (ctx().cstream) (void)hipStreamSynchronize(ctx().cstream);
+        mailbox_release();
         delete ctx().comm;
         ctx().comm = nullptr;
     }
@@ -791,9 +855,24 @@ int wl_allreduce(double *vals, int n, int op) {
     Scratch &S = global_scratch(&rc);
     WL_TRY(rc);
     WL_HIP(hipMemcpyAsync(S.st->red, vals, sizeof(double) * n, hipMemcpyHostToDevice, ctx().stream));
-    WL_TRY(cm->allreduce(S.st->red, n, op));
+    const double init = op == 0 ? 0.0 : -1e300;
+    // (np = 1: the "partials" are the values themselves; st->out doubles as the staging so that input and output differ)
+    double *in = S.st->red, *out4 = S.st->out;
+    int rc2 = 0;
+    if (ctx().mbox) {
+        WL_HIP(hipMemcpyAsync(out4, in, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx().stream));
+        switch (n) {
+            case 1: rc2 = reduce_allreduce<1>(out4, 1, op, init, in); break;
+            case 2: rc2 = reduce_allreduce<2>(out4, 1, op, init, in); break;
+            case 3: rc2 = reduce_allreduce<3>(out4, 1, op, init, in); break;
+            default: rc2 = reduce_allreduce<4>(out4, 1, op, init, in); break;
+        }
+    } else rc2 = cm->allreduce(S.st->red, n, op);
+    WL_TRY(rc2);
     WL_HIP(hipMemcpyAsync(vals, S.st->red, sizeof(double) * n, hipMemcpyDeviceToHost, ctx().stream));
     WL_HIP(hipStreamSynchronize(ctx().stream));
+    if (ctx().mbox && *ctx().mbox->err_host)
+        return fail(WL_E_STATE, "mailbox all-reduce: gave up waiting for a peer rank (is every rank still running?)", __FILE__, __LINE__);
     return 0;
 }
 
@@ -1217,6 +1296,10 @@ int wl_prof_reset(void) {
     for (auto &e : c.evts) { c.pool.push_back(e.a); c.pool.push_back(e.b); }
     c.evts.clear();
     if (c.comm) for (int q = 0; q < 6; ++q) c.comm->cnt[q] = 0;
+    return 0;
+}
+int wl_prof_reset_comm(void) {
+    if (ctx().comm) for (int q = 0; q < 6; ++q) ctx().comm->cnt[q] = 0;
     return 0;
 }
 int wl_prof_comm(int64_t out[6]) {

@@ -55,8 +55,22 @@ struct Comm {
     virtual int do_group_end() { return 0; }
 };
 
+// Mailbox all-reduce (csrc/wl_api.hip: wl_comm_mailbox): the scalars of a z-slab run -- one or two dot products per pcg!
+// iteration, each a dependency of the next kernel -- are summed through a small block of pinned HOST memory shared by the
+// ranks of the node (POSIX shared memory, registered with HIP): a rank posts its value with one system-scope store and
+// reads the others' with one poll each, ~2 PCIe round trips instead of a general-purpose collective (kernel launch +
+// ring / tree protocol) per 8 bytes.  Values are combined in RANK ORDER, so every rank computes bit-identical scalars.
+struct MboxSlot { double v[4]; unsigned long long seq; unsigned long long pad[3]; };   // 64 B: one line per (parity, rank)
+struct Mailbox {
+    MboxSlot *host = nullptr, *dev = nullptr;   // [2][nranks] slots, host mapping and the device pointer to it
+    size_t bytes = 0;
+    unsigned long long seq = 0;                 // all-reduces issued so far (identical on every rank: SPMD)
+    int *err_host = nullptr, *err_dev = nullptr;   // set by a kernel that gave up waiting for a peer
+};
+
 struct Ctx {
-    int opt[32] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 1, 1, 1, 1, 1024, 0, 0, 0, 0, 0, 0, 0};   // wl_set_option
+    Mailbox *mbox = nullptr;
+    int opt[32] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 1, 1, 1, 1, 1024, 0, 40000, 0, 0, 0, 0, 0};   // wl_set_option
     Comm *comm = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -351,6 +365,76 @@ __global__ __launch_bounds__(WL_FIN_T) void k_reduce_only(const double *partials
 }
 template <class FIN> __global__ void k_apply(const double *red, FIN fin) { fin(red); }
 
+// local reduction (exactly k_reduce_only) + the exchange through the mailbox: red[q] = op over the ranks, in rank order.
+// Slot (seq & 1, rank) is written by its owner only; a rank can be at most one all-reduce ahead of the slowest one (it
+// needs that rank's value of the current round to finish it), so two parities suffice.  Every wait is BOUNDED: after
+// WL_MBOX_SPINS polls a lane gives up, raises the error flag (the host turns it into an error at its next
+// synchronisation) and the values become NaN -- the grid always drains.
+// (bound: wl_set_option(26) thousand polls, default 40 000 000 polls x (one PCIe read + s_sleep) ~ a minute)
+constexpr int WL_MBOX_MAXRANKS = 64;
+template <int NV>
+__global__ __launch_bounds__(WL_FIN_T) void k_reduce_mbox(const double *partials, int np, int op, double init, double *red, MboxSlot *mb,
+                                                          int rank, int nranks, unsigned long long seq, int *err, long spin_limit) {
+    double acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double a = init;
+        for (int i = threadIdx.x; i < np; i += WL_FIN_T) {
+            double w = partials[(long)q * np + i];
+            a = (op == RED_SUM) ? a + w : (w > a ? w : a);
+        }
+        acc[q] = a;
+    }
+    block_red<NV, WL_FIN_T / 64>(acc, op);
+    __shared__ double got[WL_MBOX_MAXRANKS][NV];
+    MboxSlot *slots = mb + (size_t)(seq & 1ull) * (size_t)nranks;
+    if (threadIdx.x == 0) {   // post
+        MboxSlot *mine = slots + rank;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) __hip_atomic_store(&mine->v[q], acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mine->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if ((int)threadIdx.x < nranks) {   // collect: one lane per peer (the own slot included: same path, same order)
+        MboxSlot *s = slots + threadIdx.x;
+        long spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(&s->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            if (++spins > spin_limit) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+            got[threadIdx.x][q] = ok ? __hip_atomic_load(&s->v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __builtin_nan("");
+        if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            double a = got[0][q];
+            for (int r = 1; r < nranks; ++r) a = (op == RED_SUM) ? a + got[r][q] : (got[r][q] > a ? got[r][q] : a);
+            red[q] = a;
+        }
+    }
+}
+// local partials -> red[] = the value over all ranks: through the mailbox when there is one, else k_reduce_only + the
+// communicator's all-reduce (RCCL / host callbacks)
+template <int NV> inline int reduce_allreduce(const double *partials, int np, int op, double init, double *red) {
+    Comm *cm = ctx().comm;
+    Mailbox *mb = ctx().mbox;
+    if (mb && cm->size <= WL_MBOX_MAXRANKS) {
+        cm->cnt[0] += 1;
+        mb->seq += 1;
+        hipLaunchKernelGGL((k_reduce_mbox<NV>), dim3(1), dim3(WL_FIN_T), 0, ctx().stream, partials, np, op, init, red, mb->dev, cm->rank,
+                           cm->size, mb->seq, mb->err_dev, 1000L * (long)(ctx().opt[26] > 0 ? ctx().opt[26] : 1));
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL((k_reduce_only<NV>), dim3(1), dim3(WL_FIN_T), 0, ctx().stream, partials, np, op, init, red);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    return cm->allreduce(red, NV, op);
+}
+
 template <class F>
 inline int launch_range(int kclass, const Range &R, F f) {
     if (R.count() <= 0) return 0;
@@ -388,8 +472,7 @@ inline int launch_finalize(bool dist, const double *partials, int np, int op, do
         hipLaunchKernelGGL((k_finalize<NV, FIN>), dim3(1), dim3(WL_FIN_T), 0, ctx().stream, partials, np, op, init, fin);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL((k_reduce_only<NV>), dim3(1), dim3(WL_FIN_T), 0, ctx().stream, partials, np, op, init, red);
-    int rc = cm->allreduce(red, NV, op);
+    int rc = reduce_allreduce<NV>(partials, np, op, init, red);
     if (rc) return rc;
     hipLaunchKernelGGL((k_apply<FIN>), dim3(1), dim3(1), 0, ctx().stream, (const double *)red, fin);
     return (int)hipGetLastError();

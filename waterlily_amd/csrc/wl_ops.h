@@ -1267,9 +1267,7 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     auto ready = [&](const double *&part, int &n) -> int {
         if (!distr) return 0;
         Prof pr(WL_K_SCALAR, 0);
-        hipLaunchKernelGGL((k_reduce_only<1>), dim3(1), dim3(WL_FIN_T), 0, ctx().stream, part, n, (int)RED_SUM, 0.0, st->red);
-        WL_HIP(hipGetLastError());
-        WL_TRY(ctx().comm->allreduce(st->red, 1, RED_SUM));
+        WL_TRY((reduce_allreduce<1>(part, n, (int)RED_SUM, 0.0, st->red)));
         part = st->red;
         n = 1;
         return 0;

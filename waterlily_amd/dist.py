@@ -106,6 +106,7 @@ def init_rccl() -> None:
     raw = (C.c_char * 128).from_buffer_copy(obj[0])
     _lib.check(L.wl_comm_init_rccl(raw, rank, size))
     _state.update(kind="rccl", rank=rank, size=size)
+    init_mailbox()
 
 
 def host_callbacks(group=None):
@@ -163,6 +164,46 @@ def init_host(group=None) -> None:
     sr, ar, ag, rank, size = host_callbacks(group)
     _lib.check(_lib.lib().wl_comm_init_host(rank, size, sr, ar, ag, None))
     _state.update(kind="host", rank=rank, size=size, keep=(sr, ar, ag))
+    init_mailbox(group)
+
+
+def init_mailbox(group=None) -> bool:
+    """Switch the scalar all-reduces of the run to the library's mailbox (include/wlhip.h: wl_comm_mailbox): rank 0 creates a
+    POSIX shared-memory object, every rank of the node maps it.  WL_MAILBOX=0 in the environment keeps ncclAllReduce / the
+    host callbacks.  Returns whether the mailbox is active (a rank that cannot map it disables it everywhere)."""
+    import os
+    import uuid
+
+    import torch.distributed as dist
+    if os.environ.get("WL_MAILBOX", "1") == "0" or dist.get_world_size(group) < 2:
+        return False
+    L = _lib.lib()
+    rank = dist.get_rank(group)
+    name = [f"/wlhip-{os.getpid()}-{uuid.uuid4().hex[:12]}" if rank == 0 else None]
+    dist.broadcast_object_list(name, src=0, group=group)
+    ok = 1
+    if rank == 0:
+        ok = int(L.wl_comm_mailbox(name[0].encode(), 1) == 0)
+    dist.barrier(group)
+    if rank != 0:
+        ok = int(L.wl_comm_mailbox(name[0].encode(), 0) == 0)
+    oks = [None] * dist.get_world_size(group)
+    dist.all_gather_object(oks, ok, group=group)
+    if rank == 0:
+        try:
+            os.unlink("/dev/shm" + name[0])          # the mappings keep the memory alive; nothing is left behind in /dev/shm
+        except OSError:
+            pass
+    if not all(oks):                                  # all or nothing: every rank must take the same path
+        _lib.check(L.wl_comm_mailbox_off())
+        return False
+    return True
+
+
+def mailbox_active() -> bool:
+    on = C.c_int()
+    _lib.check(_lib.lib().wl_comm_mailbox_active(C.byref(on)))
+    return bool(on.value)
 
 
 def finalize() -> None:
