@@ -189,7 +189,7 @@ def main():
             wd.init_rccl()
         except Exception as e:
             print(f"[bench] rank {rank}: RCCL communicator failed: {e} | {L.wl_last_error().decode()}", file=sys.stderr, flush=True)
-            os._exit(3)   # (peers blocked inside ncclCommInitRank are torn down by the launcher)
+            os._exit(3)   # (peers still inside ncclCommInitRank leave through dist.init_rccl's watchdog, WL_COMM_TIMEOUT, or the launcher)
     elif world > 1:
         dist.init_process_group("gloo")
         wd.init_host()

@@ -94,7 +94,15 @@ def rank_size():
 
 
 def init_rccl() -> None:
-    """Bootstrap the RCCL communicator inside libwlhip.so (torch.distributed must be initialised)."""
+    """Bootstrap the RCCL communicator inside libwlhip.so (torch.distributed must be initialised).
+
+    ncclCommInitRank blocks until EVERY rank has joined: if one rank dies before it gets there the others would wait for
+    ever.  A watchdog thread bounds that wait (WL_COMM_TIMEOUT seconds, default 300, 0 = none): the process then prints the
+    reason and exits with code 5 instead of hanging -- under any launcher, not only one that reaps its ranks."""
+    import os
+    import sys
+    import threading
+
     import torch.distributed as dist
     L = _lib.lib()
     rank, size = dist.get_rank(), dist.get_world_size()
@@ -104,7 +112,21 @@ def init_rccl() -> None:
     obj = [bytes(buf)]
     dist.broadcast_object_list(obj, src=0)
     raw = (C.c_char * 128).from_buffer_copy(obj[0])
-    _lib.check(L.wl_comm_init_rccl(raw, rank, size))
+    limit = float(os.environ.get("WL_COMM_TIMEOUT", "300"))
+
+    def give_up():
+        print(f"[waterlily_amd] rank {rank}: RCCL communicator of {size} ranks not complete after {limit:.0f} s "
+              "(a peer rank failed before joining?): exiting", file=sys.stderr, flush=True)
+        os._exit(5)
+    dog = threading.Timer(limit, give_up) if limit > 0 else None
+    if dog:
+        dog.daemon = True
+        dog.start()
+    try:
+        _lib.check(L.wl_comm_init_rccl(raw, rank, size))       # (ctypes releases the GIL: the watchdog can fire meanwhile)
+    finally:
+        if dog:
+            dog.cancel()
     _state.update(kind="rccl", rank=rank, size=size)
     init_mailbox()
 
