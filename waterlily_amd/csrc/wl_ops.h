@@ -821,10 +821,8 @@ int op_correct(const G &g, T *u, const T *L, const T *x, const T *rowc = nullptr
             const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + S7_BY - 1) / S7_BY;
             const int tpp = ((ntx * nty + 7) / 8) * 8;
             const int nown = R.hi[2] - R.lo[2] + 1;
-            int want = WL_GRID / tpp;
-            if (want < 1) want = 1;
-            if (want > nown) want = nown;
-            const int clen = (nown + want - 1) / want, nchunk = (nown + clen - 1) / clen;
+            int clen, nchunk;
+            chunking(tpp, nown, 0, ctx().opt[28], &clen, &nchunk);   // wl_set_option(28): grid size in units of 1024 workgroups
             Prof p(WL_K_CORRECT, R.count());
             const XBc<T> xb = (xbc && xbc->on) ? *xbc : XBc<T>{0, 0, (T)0};
             hipLaunchKernelGGL((k_correct3<T>), dim3(tpp * nchunk), dim3(64 * S7_BY), 0, ctx().stream, g, u, L, x, rowc, ntx, tpp,
