@@ -222,12 +222,23 @@ int wl_mg_update_changed(wl_mg *m, wl_flow *a);
  *   family WL_BODY_PLATE : p = {a, thk}              sdf = norm(xi - (clamp(xi0,-a,a), 0[, 0])) - thk   (the reference's
  *                                                    test plate, test/maintests.jl:375: a stadium / capsule about the xi0 axis)
  * Matrices are row-major 3x3 (the upper-left 2x2 block when D == 2). */
-enum { WL_BODY_SPHERE = 0, WL_BODY_TORUS = 1, WL_BODY_PLATE = 2 };
+enum { WL_BODY_SPHERE = 0, WL_BODY_TORUS = 1, WL_BODY_PLATE = 2, WL_BODY_CYLINDER = 3 };
+/*   family WL_BODY_CYLINDER: p = {c0, c1, c2, radius, m0, m1, m2}  sdf = sqrt(sum_a m_a != 0 (xi_a - c_a)^2) - radius: a circle
+ *                                                    extruded along the axes whose m_a is 0 (the 3-D cylinder of the reference's
+ *                                                    examples/ThreeD_cylinder*.jl)
+ * A body may be a COMPOSITE: an array of up to WL_BODY_MAXLEAF descriptors combined left to right like the reference's
+ * `Bodies(bodies, ops)` (src/AutoBody.jl:40-110; the AutoBody operators +, ∪, ∩, - of :22-34 build the same thing):
+ * element 0 carries `count`, element l > 0 its operation `op` against the composite of the elements before it.  The
+ * distance is the min / max of the leaves' distances; normal, map and velocity are those of the ACTIVE leaf (:73-93). */
+enum { WL_BODY_OP_UNION = 0, WL_BODY_OP_MINUS = 1, WL_BODY_OP_INTERSECT = 2 };
+#define WL_BODY_MAXLEAF 6
 typedef struct wl_body_desc {
     int32_t family;
     int32_t identity_map;   /* != 0: xi = x (A, b, dA, db, Ainv are ignored; V = 0) */
     double p[8];
     double A[9], b[3], dA[9], db[3], Ainv[9];
+    int32_t op;             /* elements 1.. of a composite: WL_BODY_OP_* */
+    int32_t count;          /* element 0: number of descriptors in the array (0 is read as 1) */
 } wl_body_desc;
 /* Part 1: sigma = sdf at every interior cell centre (Body.jl:34) and the number of band cells d^2 < (2+eps)^2 (:35)
  * this rank will report (synchronises).  Part 2 (same body / eps): mu0, mu1, V (:36-48), then BC!(mu0,0) and

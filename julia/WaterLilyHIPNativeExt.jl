@@ -281,14 +281,16 @@ function measure!(a::Flow{N,T,<:HIPArray}, body::AbstractBody; t=zero(T), ϵ=1) 
     chk(ccall((:wl_flow_update, lib), Cint, (Ptr{Cvoid},), handle(a)))                          # rebuild the body-free row flags
 end
 # ---- parametric bodies: closed-form sdf family + affine map  =>  the whole measure! runs in the library (csrc/wl_measure.h)
-struct WlBody            # == wl_body_desc
+struct WlBody            # == wl_body_desc (one leaf; a composite is a Vector{WlBody}: element 1 carries count, the others op)
     family::Int32; identity_map::Int32; p::NTuple{8,Cdouble}
     A::NTuple{9,Cdouble}; b::NTuple{3,Cdouble}; dA::NTuple{9,Cdouble}; db::NTuple{3,Cdouble}; Ainv::NTuple{9,Cdouble}
+    op::Int32; count::Int32
 end
 """
     ParametricBody(family, params; map=nothing)
 
-`family` ∈ (:sphere, :torus, :plate) with `params` = (c..., radius) | (c₁,c₂,c₃,R,r) | (a, thk) (include/wlhip.h);
+`family` ∈ (:sphere, :torus, :plate, :cylinder) with `params` = (c..., radius) | (c₁,c₂,c₃,R,r) | (a, thk) |
+(c₁,c₂,c₃,radius,m₁,m₂,m₃) (include/wlhip.h);
 `map(t)` returns the affine map ξ = A x + b at time t as `(A, b)` (D×D matrix, D-vector).  Its time derivative comes from
 ForwardDiff, like `measure` gets `dot` (src/AutoBody.jl:128).  `sdf`/`measure` fall back to the equivalent `AutoBody`, so
 every generic code path (host `measure!`, `nds`, plotting) still works.
@@ -309,12 +311,20 @@ WaterLily.measure(b::ParametricBody, x, t; kw...) = WaterLily.measure(b.auto, x,
 pad9(M, D) = ntuple(q -> ((r, c) = divrem(q - 1, 3); (r < D && c < D) ? Float64(M[r+1, c+1]) : 0.0), 9)   # row-major 3x3
 pad3(v, D) = ntuple(q -> q <= D ? Float64(v[q]) : 0.0, 3)
 function desc(body::ParametricBody, t, D)
-    fam = Int32(body.family == :sphere ? 0 : body.family == :torus ? 1 : 2)
+    fam = Int32(body.family == :sphere ? 0 : body.family == :torus ? 1 : body.family == :plate ? 2 : 3)
     p8 = ntuple(q -> q <= length(body.params) ? body.params[q] : 0.0, 8)
-    body.map === nothing && return WlBody(fam, 1, p8, pad9(I(D), D), pad3(zeros(D), D), pad9(zeros(D, D), D), pad3(zeros(D), D), pad9(I(D), D))
+    body.map === nothing && return WlBody(fam, 1, p8, pad9(I(D), D), pad3(zeros(D), D), pad9(zeros(D, D), D), pad3(zeros(D), D), pad9(I(D), D), 0, 1)
     A, b = body.map(t)
     dA = WaterLily.ForwardDiff.derivative(τ -> body.map(τ)[1], t); db = WaterLily.ForwardDiff.derivative(τ -> body.map(τ)[2], t)
-    WlBody(fam, 0, p8, pad9(A, D), pad3(b, D), pad9(dA, D), pad3(db, D), pad9(inv(A), D))
+    WlBody(fam, 0, p8, pad9(A, D), pad3(b, D), pad9(dA, D), pad3(db, D), pad9(inv(A), D), 0, 1)
+end
+# `Bodies` of parametric leaves (src/AutoBody.jl:40-110) -> one descriptor array: a maintainer would dispatch
+# measure!(::Flow{N,T,<:HIPArray}, ::Bodies) here when every leaf is a ParametricBody, passing Vector{WlBody} to the same entry points
+opcode(f) = (f === Base.:+ || f === Base.:∪) ? Int32(0) : f === Base.:- ? Int32(1) : Int32(2)
+function desc(leaves::Vector{<:ParametricBody}, ops, t, D)
+    v = [desc(b, t, D) for b in leaves]
+    [WlBody(d.family, d.identity_map, d.p, d.A, d.b, d.dA, d.db, d.Ainv, l == 1 ? Int32(0) : opcode(ops[l-1]), l == 1 ? Int32(length(v)) : Int32(0))
+     for (l, d) in enumerate(v)]
 end
 const BAND = IdDict{Any,Any}()       # flow => (t, band cells) of the last native measure!
 function measure!(a::Flow{N,T,<:HIPArray}, body::ParametricBody; t=zero(T), ϵ=1) where {N,T}     # src/Body.jl:31-53, all on the device

@@ -27,7 +27,7 @@ import math
 
 import numpy as np
 
-__all__ = ["Sphere", "Torus", "Plate", "Identity", "Translate", "Rotate2D", "Bend2D", "Body", "measure", "sdf",
+__all__ = ["Sphere", "Cylinder", "Torus", "Plate", "Bodies", "Identity", "Translate", "Rotate2D", "Bend2D", "Body", "measure", "sdf",
            "measure_fields", "nds_band", "mu0", "mu1", "kern"]
 
 
@@ -50,6 +50,29 @@ class Sphere:
         e = self._e(xi)
         with np.errstate(invalid="ignore", divide="ignore"):
             return e / np.sqrt((e ** 2).sum(0))          # 0/0 = NaN at the centre, like ForwardDiff
+
+
+class Cylinder:
+    """sqrt(sum over `axes` of (xi - center)^2) - radius: a circle extruded along the other axes (the reference's 3-D
+    cylinder examples: `norm2(x[1:2] .- center) - radius`).  Derivatives along the extrusion axes are exactly 0."""
+
+    def __init__(self, center, radius, axes=(0, 1)):
+        self.c, self.R, self.axes = center, float(radius), tuple(axes)
+
+    def _e(self, xi):
+        c = np.broadcast_to(np.asarray(self.c, dtype=np.float64), (xi.shape[0],))
+        e = np.zeros_like(xi)
+        for a in self.axes:
+            e[a] = xi[a] - c[a]
+        return e
+
+    def val(self, xi, t):
+        return np.sqrt((self._e(xi) ** 2).sum(0)) - self.R
+
+    def grad(self, xi, t):
+        e = self._e(xi)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return e / np.sqrt((e ** 2).sum(0))
 
 
 class Torus:
@@ -186,8 +209,43 @@ class Body:
         self.shape, self.map = shape, (map if map is not None else Identity())
 
 
+class Bodies:
+    """Bodies(bodies, ops) (src/AutoBody.jl:40-66): `bodies` are Body objects, ops[i-1] in "+", "-", "&" ("∪", "∩") joins
+    bodies[i] to the composite of the ones before it"""
+
+    def __init__(self, bodies, ops=None):
+        self.bodies = list(bodies)
+        self.ops = ["+"] * (len(self.bodies) - 1) if ops is None else list(ops)
+        assert len(self.bodies) == len(self.ops) + 1
+
+
+def _active(bodies: "Bodies", xp, t):
+    """sdf_map_d / reduce_sdf_map (src/AutoBody.jl:73-93): per point the composite distance, the index of the leaf whose
+    sdf and map are taken, and the sign of that sdf (-1 after a minus)"""
+    d = sdf(bodies.bodies[0], xp, t)
+    act = np.zeros(d.shape, dtype=np.int64)
+    sgn = np.ones(d.shape)
+    for i, (b, op) in enumerate(zip(bodies.bodies[1:], bodies.ops), start=1):
+        db = sdf(b, xp, t)
+        if op in ("+", "∪", "|"):
+            take, new, s = db < d, db, 1.0
+        elif op == "-":
+            take, new, s = -db > d, -db, -1.0
+        else:
+            take, new, s = db > d, db, 1.0
+        d = np.where(take, new, d)
+        act = np.where(take, i, act)
+        sgn = np.where(take, s, sgn)
+    return d, act, sgn
+
+
 # ------------------------------------------------------------------ AutoBody.jl:38,115-131
-def sdf(body: Body, x, t=0.0):
+def sdf(body, x, t=0.0):
+    if isinstance(body, Bodies):                              # AutoBody.jl:99
+        x = np.asarray(x, dtype=np.float64)
+        single = x.ndim == 1
+        d = _active(body, x[:, None] if single else x, float(t))[0]
+        return d[0] if single else d
     x = np.asarray(x, dtype=np.float64)
     single = x.ndim == 1
     xp = x[:, None] if single else x
@@ -195,8 +253,24 @@ def sdf(body: Body, x, t=0.0):
     return d[0] if single else d
 
 
-def measure(body: Body, x, t=0.0, fastd2=math.inf):
+def measure(body, x, t=0.0, fastd2=math.inf):
     """returns (d, n, V); n = V = 0 where d^2 > fastd2 (:118) or where the gradient has a NaN (:120)"""
+    if isinstance(body, Bodies):                              # AutoBody.jl:107-110: measure(sdf, map) of the active leaf
+        x = np.asarray(x, dtype=np.float64)
+        single = x.ndim == 1
+        xp = x[:, None] if single else x
+        d, act, sgn = _active(body, xp, float(t))
+        n, V = np.zeros(xp.shape), np.zeros(xp.shape)
+        for i, b in enumerate(body.bodies):
+            q = np.nonzero(act == i)[0]
+            if not q.size:
+                continue
+            # the leaf's own measure with its sdf negated after a minus: d -> -d, grad -> -grad (|grad| and V unchanged)
+            di, ni, Vi = measure(b, xp[:, q], t, fastd2=fastd2)
+            d[q], n[:, q], V[:, q] = sgn[q] * di, sgn[q] * ni, Vi
+        if single:
+            return d[0], n[:, 0], V[:, 0]
+        return d, n, V
     x = np.asarray(x, dtype=np.float64)
     single = x.ndim == 1
     xp = x[:, None] if single else x

@@ -536,7 +536,7 @@ class Simulation:
         self.L, self.eps = L, eps
         if body is not None and measure_fn is None:
             from . import geometry as _G
-            assert isinstance(body, _G.Body), "give an oracle.geometry.Body, or measure_fn/nds_fn for any other body"
+            assert isinstance(body, (_G.Body, _G.Bodies)), "give an oracle.geometry.Body / Bodies, or measure_fn/nds_fn for any other body"
             measure_fn, nds_fn = _G.measure_fields, _G.nds_band
         self.body, self._measure_fn, self._nds_fn = body, measure_fn, nds_fn
         self.flow = Flow(dims, u_BC, ulam=ulam, dt=dt, nu=nu, g=g, T=T, perdir=perdir, exitBC=exitBC)

@@ -30,6 +30,33 @@ def sphere(center, radius):
                 lambda D: B.Sphere(center, radius, D))
 
 
+def cylinder(center, radius, D=3):
+    """circle extruded along the last axis: the reference's 3-D cylinder examples, norm2(x[1:2] .- center) - radius"""
+    ax = tuple(range(D - 1))
+    return Twin(AutoBody(lambda x, t: torch.sqrt(sum((x[i] - center) ** 2 for i in ax)) - radius),
+                G.Body(G.Cylinder(center, radius, ax)), lambda Dn: B.Cylinder(center, radius, Dn))
+
+
+def drilled_sphere(c=13.0, R=8.0, hole=3.0, cut=(13.0, 13.0, 17.5), v=0.0):
+    """(sphere - cylinder) ∩ sphere2, the first sphere translating along x with speed v: AutoBody's -, ∩ (AutoBody.jl:22-34)
+    as closures, the reference's `Bodies` (AutoBody.jl:40-110) on the oracle side and as a native composite"""
+    mv = _shift(lambda t: v * t) if v else None
+    vv = (v, 0.0, 0.0)
+    prod = (AutoBody(lambda x, t: norm2(x - c) - R, mv) - AutoBody(lambda x, t: torch.sqrt((x[0] - c) ** 2 + (x[1] - c) ** 2) - hole)) \
+        & AutoBody(lambda x, t: torch.sqrt(sum((x[i] - cut[i]) ** 2 for i in range(3))) - R)
+    orc = G.Bodies([G.Body(G.Sphere(c, R), G.Translate(v=vv) if v else None), G.Body(G.Cylinder(c, hole, (0, 1))),
+                    G.Body(G.Sphere(cut, R))], ["-", "&"])
+    nat = lambda D: (B.Sphere(c, R, 3, map=B.translation(3, v=vv) if v else None) - B.Cylinder(c, hole, 3)) & B.Sphere(cut, R, 3)
+    return Twin(prod, orc, nat)
+
+
+def two_circles(v=1.5):
+    """union of a fixed and a translating circle (2-D)"""
+    prod = AutoBody(lambda x, t: norm2(x - 11.0) - 4.0) + AutoBody(lambda x, t: norm2(x - 14.3) - 3.1, _shift(lambda t: v * t))
+    orc = G.Bodies([G.Body(G.Sphere(11.0, 4.0)), G.Body(G.Sphere(14.3, 3.1), G.Translate(v=(v, 0.0)))], ["+"])
+    return Twin(prod, orc, lambda D: B.Sphere(11.0, 4.0, 2) + B.Sphere(14.3, 3.1, 2, map=B.translation(2, v=(v, 0.0))))
+
+
 def torus(c, R, r):
     def sdf(x, t):
         q = torch.sqrt((x[1] - c) ** 2 + (x[2] - c) ** 2) - R

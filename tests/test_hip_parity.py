@@ -871,7 +871,12 @@ def test_native_measure_matches_oracle(T):
              ((48, 32), bodies.moving_circle(14.0, 6.0, v=3.0, a=2.0), (0.0, 0.5, 2.5)),
              ((40, 40), bodies.rotating_circle(9.0, 5.0, 20.0, 0.4, 1.0), (0.0, 1.7)),
              ((32, 32), bodies.rotating_plate(8), (0.0, 0.6, 2.3)),
-             ((m, m, m), bodies.moving_circle(12.0, 4.0, a=2.0, D=3), (0.3, 1.2))]
+             ((m, m, m), bodies.moving_circle(12.0, 4.0, a=2.0, D=3), (0.3, 1.2)),
+             # the cylinder family and native COMPOSITES (the reference's `Bodies`, AutoBody.jl:40-110): difference +
+             # intersection of three leaves with one of them moving; union of a fixed and a moving circle
+             ((m, m, 16), bodies.cylinder(14.0, 5.0), (0.0,)),
+             ((m, m, m), bodies.drilled_sphere(v=0.7), (0.0, 1.3)),
+             ((48, 32), bodies.two_circles(), (0.0, 2.0))]
     eps = geom_tol(T)
     for dims, tw, times in cases:
         D = len(dims)

@@ -91,6 +91,14 @@ def _cases():
                   G.Body(G.Sphere(2 * r, r), G.Translate(a=(2.0, 0.0))), (0.0, 0.5)),
         "plate_rotate": ((32, 32), AutoBody(plate, rotate), G.Body(G.Plate(r - 2, 2.0), G.Rotate2D(2 * r, 1 / r, 1.0)), (0.0, 0.6)),
         "plate_bend": ((32, 32), AutoBody(plate, bend), G.Body(G.Plate(r - 2, 2.0), G.Bend2D(2 * r, 2 / r ** 2, 0.2 / r)), (0.0, 0.6)),
+        # the 3-D cylinder of the reference's examples (norm2(x[1:2] .- c) - R) and AutoBody set operations / `Bodies`
+        # (AutoBody.jl:22-34,40-110): the product side as closures combined with +, -, ∩; the oracle side as G.Bodies
+        "cylinder": ((24, 24, 12), B.Cylinder(11.0, 4.0, 3), G.Body(G.Cylinder(11.0, 4.0, (0, 1))), (0.0,)),
+        "union_move": ((40, 24), AutoBody(lambda x, t: norm2(x - 9.0) - 4.0) + AutoBody(lambda x, t: norm2(x - 12.3) - 3.1, lambda x, t: x - _vec(t, 1.5 * t, 0.0)),
+                       G.Bodies([G.Body(G.Sphere(9.0, 4.0)), G.Body(G.Sphere(12.3, 3.1), G.Translate(v=(1.5, 0.0)))], ["+"]), (0.0, 2.0)),   # (no exact ties between the leaves)
+        "sphere_minus_cyl_and": ((24, 24, 24), (B.Sphere(11.0, 7.0, 3) - B.Cylinder(11.0, 3.0, 3)) & B.Sphere((11.0, 11.0, 14.0), 7.0, 3),
+                                 G.Bodies([G.Body(G.Sphere(11.0, 7.0)), G.Body(G.Cylinder(11.0, 3.0, (0, 1))), G.Body(G.Sphere((11.0, 11.0, 14.0), 7.0))],
+                                          ["-", "&"]), (0.0,)),
     }
 
 
@@ -110,7 +118,7 @@ def test_product_host_geometry_matches_oracle(name, T):
             scale = max(1.0, float(np.abs(w).max()))
             assert np.abs(g.astype(np.float64) - w).max() <= tol * scale, (name, nm, t)
         assert np.abs(want[1]).max() > 0.1                                 # the case does exercise the band ...
-        assert name in ("circle", "sphere", "torus") or t == 0.0 or np.abs(want[2]).max() > 0.1   # ... and the body velocity
+        assert name in ("circle", "sphere", "torus", "cylinder", "sphere_minus_cyl_and") or t == 0.0 or np.abs(want[2]).max() > 0.1   # ... and the body velocity
 
 
 @pytest.mark.parametrize("name", ["circle", "sphere", "torus", "accel"])

@@ -40,10 +40,13 @@ class FlowDesc(C.Structure):
 class BodyDesc(C.Structure):
     """wl_body_desc (include/wlhip.h): a parametric body at one instant"""
     _fields_ = [("family", C.c_int32), ("identity_map", C.c_int32), ("p", C.c_double * 8), ("A", C.c_double * 9),
-                ("b", C.c_double * 3), ("dA", C.c_double * 9), ("db", C.c_double * 3), ("Ainv", C.c_double * 9)]
+                ("b", C.c_double * 3), ("dA", C.c_double * 9), ("db", C.c_double * 3), ("Ainv", C.c_double * 9),
+                ("op", C.c_int32), ("count", C.c_int32)]
 
 
-WL_BODY_SPHERE, WL_BODY_TORUS, WL_BODY_PLATE = 0, 1, 2
+WL_BODY_SPHERE, WL_BODY_TORUS, WL_BODY_PLATE, WL_BODY_CYLINDER = 0, 1, 2, 3
+WL_BODY_OP_UNION, WL_BODY_OP_MINUS, WL_BODY_OP_INTERSECT = 0, 1, 2
+WL_BODY_MAXLEAF = 6
 
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)

@@ -44,7 +44,8 @@ class AutoBody:
     # AutoBody.jl:22-34 set operations
     def __add__(a, b: "AutoBody") -> "AutoBody":
         mp = lambda x, t: torch.where(a.sdf(x, t) < b.sdf(x, t), a.map(x, t), b.map(x, t))
-        sd = lambda x, t: torch.minimum(a.sdf(x, t), b.sdf(x, t))
+        # (Julia's min(x,y) = ifelse(isless(y,x), y, x): at a tie the value AND the derivative of x -- torch.minimum would split the gradient)
+        sd = lambda x, t: (lambda sa, sb: torch.where(sb < sa, sb, sa))(a.sdf(x, t), b.sdf(x, t))
         out = AutoBody(sd, mp, compose=False)
         out.identity_map = a.identity_map and b.identity_map
         return out
@@ -53,7 +54,7 @@ class AutoBody:
 
     def __and__(a, b: "AutoBody") -> "AutoBody":
         mp = lambda x, t: torch.where(a.sdf(x, t) > b.sdf(x, t), a.map(x, t), b.map(x, t))
-        sd = lambda x, t: torch.maximum(a.sdf(x, t), b.sdf(x, t))
+        sd = lambda x, t: (lambda sa, sb: torch.where(sa < sb, sb, sa))(a.sdf(x, t), b.sdf(x, t))
         out = AutoBody(sd, mp, compose=False)
         out.identity_map = a.identity_map and b.identity_map
         return out
@@ -135,9 +136,7 @@ class ParametricBody(AutoBody):
         super().__init__(sdf_closure, map)
         self.params, self.amap = [float(v) for v in params], map
 
-    def native_desc(self, t: float, D: int):
-        from ._lib import BodyDesc
-        d = BodyDesc()
+    def _fill_desc(self, d, t: float, D: int) -> None:
         d.family, d.identity_map = self.family, int(self.amap is None)
         for q, v in enumerate(self.params):
             d.p[q] = v
@@ -151,7 +150,87 @@ class ParametricBody(AutoBody):
             full = np.zeros(3)
             full[:D] = vec
             getattr(d, name)[:] = list(full)
-        return d
+
+    def native_desc(self, t: float, D: int):
+        """the wl_body_desc array (one element) the HIP measure! kernels take"""
+        from ._lib import BodyDesc
+        arr = (BodyDesc * 1)()
+        self._fill_desc(arr[0], t, D)
+        arr[0].count = 1
+        return arr
+
+    # set operations on parametric bodies stay parametric: a `Bodies` composite the HIP kernels measure natively
+    def __add__(a, b):
+        return Bodies([a], []) + b if isinstance(b, (ParametricBody, Bodies)) else AutoBody.__add__(a, b)
+
+    __or__ = __add__
+
+    def __and__(a, b):
+        return Bodies([a], []) & b if isinstance(b, (ParametricBody, Bodies)) else AutoBody.__and__(a, b)
+
+    def __sub__(a, b):
+        return Bodies([a], []) - b if isinstance(b, (ParametricBody, Bodies)) else AutoBody.__sub__(a, b)
+
+
+class Bodies(AutoBody):
+    """`Bodies(bodies, ops)` (src/AutoBody.jl:40-110) of PARAMETRIC leaves: combined left to right, ops[i-1] in "+", "-", "&"
+    ("∪" = "+", "∩" = "&") between the composite of bodies[:i] and bodies[i].  Its torch closures (generic path) are the fold
+    of the AutoBody operators (AutoBody.jl:22-34); on the device the whole composite is ONE wl_body_desc array."""
+    _OPS = {"+": 0, "∪": 0, "|": 0, "-": 1, "&": 2, "∩": 2}
+
+    def __init__(self, bodies, ops=None):
+        bodies = list(bodies)
+        ops = ["+"] * (len(bodies) - 1) if ops is None else list(ops)
+        if len(bodies) != len(ops) + 1:
+            raise ValueError("length(bodies) != length(ops)+1")
+        if any(o not in self._OPS for o in ops):
+            raise ValueError("Operations array `ops` not supported. Use only `ops ∈ [+,-,∩,∪]`")
+        if not all(isinstance(b, ParametricBody) for b in bodies):
+            raise TypeError("Bodies takes parametric leaves (Sphere, Cylinder, Torus, Plate); closures combine through AutoBody's operators")
+        self.bodies, self.ops = bodies, ops
+        acc = bodies[0]
+        for b, o in zip(bodies[1:], ops):
+            f = {0: AutoBody.__add__, 1: AutoBody.__sub__, 2: AutoBody.__and__}[self._OPS[o]]
+            acc = f(acc, b)
+        self.sdf, self.map, self.identity_map = acc.sdf, acc.map, acc.identity_map
+
+    def _with(self, other, op):
+        if isinstance(other, ParametricBody):
+            return Bodies(self.bodies + [other], self.ops + [op])
+        if isinstance(other, Bodies):
+            if op != "+" and len(other.bodies) > 1:     # (a - (b + c)) is not a left fold of the leaves: closures only
+                return {"-": AutoBody.__sub__, "&": AutoBody.__and__}[op](self, other)
+            return Bodies(self.bodies + other.bodies, self.ops + [op] + other.ops)
+        return {"+": AutoBody.__add__, "-": AutoBody.__sub__, "&": AutoBody.__and__}[op](self, other)
+
+    def __add__(self, other):
+        return self._with(other, "+")
+
+    __or__ = __add__
+
+    def __and__(self, other):
+        return self._with(other, "&")
+
+    def __sub__(self, other):
+        return self._with(other, "-")
+
+    def native_desc(self, t: float, D: int):
+        from ._lib import WL_BODY_MAXLEAF, BodyDesc
+        n = len(self.bodies)
+        if n > WL_BODY_MAXLEAF:
+            raise ValueError(f"a native composite holds at most {WL_BODY_MAXLEAF} leaves")
+        arr = (BodyDesc * n)()
+        for l, b in enumerate(self.bodies):
+            b._fill_desc(arr[l], t, D)
+            arr[l].op = self._OPS[self.ops[l - 1]] if l else 0
+        arr[0].count = n
+        return arr
+
+
+def is_native(body) -> bool:
+    """can the HIP measure! kernels take this body? (a parametric leaf or a composite of at most WL_BODY_MAXLEAF of them)"""
+    from ._lib import WL_BODY_MAXLEAF
+    return isinstance(body, ParametricBody) or (isinstance(body, Bodies) and len(body.bodies) <= WL_BODY_MAXLEAF)
 
 
 class Sphere(ParametricBody):
@@ -166,6 +245,22 @@ class Sphere(ParametricBody):
         def sdf_closure(x, t):
             return torch.sqrt(sum((x[i] - cl[i]) ** 2 for i in range(D))) - radius
         super().__init__(sdf_closure, list(np.concatenate([c, np.zeros(3 - D)])) + [radius], map)
+
+
+class Cylinder(ParametricBody):
+    """sqrt(sum over the axes in `axes` of (x - center)^2) - radius: a circle extruded along the remaining axes (default: the
+    last one) -- the 3-D cylinder of the reference's examples/ThreeD_cylinder*.jl, `norm2(x[1:2] .- center) - radius`."""
+    family = 3
+
+    def __init__(self, center, radius, D: int = 3, axes=None, map: Optional[AffineMap] = None):
+        axes = tuple(range(D - 1)) if axes is None else tuple(int(a) for a in axes)
+        c = np.broadcast_to(np.asarray(center, dtype=np.float64), (D,)).copy()
+        cl = [float(v) for v in c]
+        mask = [1.0 if a in axes else 0.0 for a in range(3)]
+
+        def sdf_closure(x, t):
+            return torch.sqrt(sum((x[i] - cl[i]) ** 2 for i in axes)) - radius
+        super().__init__(sdf_closure, list(np.concatenate([c, np.zeros(3 - D)])) + [radius] + mask, map)
 
 
 class Torus(ParametricBody):

@@ -633,12 +633,18 @@ template <class T, int D> static int flow_update(wl_flow *a) {
     a->prev_valid = false;   // the arrays were written by someone else: the next native measure! rewrites every row
     return flow_compact_busy(a, g, D);
 }
-static BodyDev body_dev(const wl_body_desc *b) {
+static BodyDev body_dev(const wl_body_desc *bodies) {
     BodyDev o;
-    o.family = b->family; o.ident = b->identity_map != 0;
-    for (int q = 0; q < 8; ++q) o.p[q] = b->p[q];
-    for (int q = 0; q < 9; ++q) { o.A[q] = b->A[q]; o.dA[q] = b->dA[q]; o.Ainv[q] = b->Ainv[q]; }
-    for (int q = 0; q < 3; ++q) { o.b[q] = b->b[q]; o.db[q] = b->db[q]; }
+    o.n = bodies[0].count > 0 ? bodies[0].count : 1;
+    for (int l = 0; l < o.n; ++l) {
+        const wl_body_desc *b = bodies + l;
+        LeafDev &d = o.leaf[l];
+        d.family = b->family; d.ident = b->identity_map != 0; d.op = b->op;
+        for (int q = 0; q < 8; ++q) d.p[q] = b->p[q];
+        for (int q = 0; q < 9; ++q) { d.A[q] = b->A[q]; d.dA[q] = b->dA[q]; d.Ainv[q] = b->Ainv[q]; }
+        for (int q = 0; q < 3; ++q) { d.b[q] = b->b[q]; d.db[q] = b->db[q]; }
+    }
+    for (int l = o.n; l < WL_BODY_MAXLEAF; ++l) o.leaf[l] = o.leaf[0];
     return o;
 }
 static int measure_alloc(wl_flow *a, size_t nrows) {
@@ -705,9 +711,16 @@ template <class T, int D> static int measure_fill(wl_flow *a, const wl_body_desc
 }
 static int check_body(const wl_body_desc *b, int D) {
     if (!b) return fail(WL_E_ARG, "null body", __FILE__, __LINE__);
-    if (b->family != WL_BODY_SPHERE && b->family != WL_BODY_TORUS && b->family != WL_BODY_PLATE)
-        return fail(WL_E_ARG, "unknown body family", __FILE__, __LINE__);
-    if (b->family == WL_BODY_TORUS && D != 3) return fail(WL_E_ARG, "the torus family needs D == 3", __FILE__, __LINE__);
+    const int n = b[0].count > 0 ? b[0].count : 1;
+    if (n > WL_BODY_MAXLEAF) return fail(WL_E_ARG, "more than WL_BODY_MAXLEAF leaves in a composite body", __FILE__, __LINE__);
+    for (int l = 0; l < n; ++l) {
+        const int f = b[l].family;
+        if (f != WL_BODY_SPHERE && f != WL_BODY_TORUS && f != WL_BODY_PLATE && f != WL_BODY_CYLINDER)
+            return fail(WL_E_ARG, "unknown body family", __FILE__, __LINE__);
+        if (f == WL_BODY_TORUS && D != 3) return fail(WL_E_ARG, "the torus family needs D == 3", __FILE__, __LINE__);
+        if (l > 0 && (b[l].op < WL_BODY_OP_UNION || b[l].op > WL_BODY_OP_INTERSECT))
+            return fail(WL_E_ARG, "unknown composite operation", __FILE__, __LINE__);
+    }
     return 0;
 }
 // shared driver of the band reductions (pressure_force / viscous_force / pressure_moment)

@@ -24,13 +24,21 @@
 
 namespace wl {
 
-struct BodyDev {
+struct LeafDev {
     int family, ident;        // wl_body_desc.family; ident: the map is the identity
+    int op;                   // how this leaf joins the running composite (WL_BODY_OP_*; ignored for leaf 0)
     double p[8];
     double A[9], b[3], dA[9], db[3], Ainv[9];   // row-major 3x3
 };
+// Up to WL_BODY_MAXLEAF leaves combined left to right like the reference's `Bodies` (src/AutoBody.jl:57-93, and the
+// AutoBody operators :22-34): union takes the smaller distance, intersection the larger, minus max(d, -d_leaf); geometry
+// (gradient, map, velocity) is that of the ACTIVE leaf, its sdf negated after a minus.
+struct BodyDev {
+    int n;
+    LeafDev leaf[WL_BODY_MAXLEAF];
+};
 
-template <int D> __device__ __forceinline__ void body_map(const BodyDev &B, const double (&x)[D], double (&xi)[D]) {
+template <int D> __device__ __forceinline__ void body_map(const LeafDev &B, const double (&x)[D], double (&xi)[D]) {
     if (B.ident) {
 #pragma unroll
         for (int a = 0; a < D; ++a) xi[a] = x[a];
@@ -45,7 +53,7 @@ template <int D> __device__ __forceinline__ void body_map(const BodyDev &B, cons
     }
 }
 // sdf(xi) and its gradient with respect to xi (closed forms of what ForwardDiff.gradient returns)
-template <int D> __device__ __forceinline__ double body_sdf(const BodyDev &B, const double (&xi)[D], double (&g)[D], bool want_grad) {
+template <int D> __device__ __forceinline__ double leaf_sdf(const LeafDev &B, const double (&xi)[D], double (&g)[D], bool want_grad) {
     if (B.family == WL_BODY_TORUS && D == 3) {   // norm((e1, norm((e2,e3)) - R)) - r
         const double e0 = xi[0] - B.p[0], e1 = xi[1] - B.p[1], e2 = xi[D - 1] - B.p[2];
         const double s = sqrt(e1 * e1 + e2 * e2), q = s - B.p[3];
@@ -69,10 +77,12 @@ template <int D> __device__ __forceinline__ double body_sdf(const BodyDev &B, co
         }
         return rho - B.p[1];
     }
-    // WL_BODY_SPHERE: sqrt(sum(abs2, xi - c)) - R
+    // WL_BODY_SPHERE: sqrt(sum(abs2, xi - c)) - R;  WL_BODY_CYLINDER: the same over the axes with p[4+a] != 0 (the
+    // others do not enter: an infinite cylinder / a slab-less disc along them)
     double e[D], s2 = 0;
+    const bool cyl = B.family == WL_BODY_CYLINDER;
 #pragma unroll
-    for (int a = 0; a < D; ++a) { e[a] = xi[a] - B.p[a]; s2 += e[a] * e[a]; }
+    for (int a = 0; a < D; ++a) { e[a] = (cyl && B.p[4 + a] == 0.0) ? 0.0 : xi[a] - B.p[a]; s2 += e[a] * e[a]; }
     const double rho = sqrt(s2);
     if (want_grad) {
 #pragma unroll
@@ -80,16 +90,39 @@ template <int D> __device__ __forceinline__ double body_sdf(const BodyDev &B, co
     }
     return rho - B.p[3];
 }
-// measure(body, x, t; fastd2)  src/AutoBody.jl:115-131
+// the composite's distance at x and which leaf is active (sdf_map_d / reduce_sdf_map, src/AutoBody.jl:73-93); sgn = -1
+// when the active leaf entered through a minus
+template <int D> __device__ __forceinline__ double body_sdf(const BodyDev &B, const double (&x)[D], int &act, double &sgn) {
+    double xi[D], g[D];
+    body_map<D>(B.leaf[0], x, xi);
+    double d = leaf_sdf<D>(B.leaf[0], xi, g, false);
+    act = 0; sgn = 1.0;
+    for (int q = 1; q < B.n; ++q) {
+        body_map<D>(B.leaf[q], x, xi);
+        const double dq = leaf_sdf<D>(B.leaf[q], xi, g, false);
+        const int op = B.leaf[q].op;
+        if (op == WL_BODY_OP_UNION) { if (dq < d) { d = dq; act = q; sgn = 1.0; } }
+        else if (op == WL_BODY_OP_MINUS) { if (-dq > d) { d = -dq; act = q; sgn = -1.0; } }
+        else { if (dq > d) { d = dq; act = q; sgn = 1.0; } }
+    }
+    return d;
+}
+template <int D> __device__ __forceinline__ double body_sdf(const BodyDev &B, const double (&x)[D]) {
+    int act; double sgn;
+    return body_sdf<D>(B, x, act, sgn);
+}
+// measure(body, x, t; fastd2)  src/AutoBody.jl:115-131 (for `Bodies`: :107-110 -- measure of the active leaf's sdf and map)
 template <int D>
-__device__ __forceinline__ void body_measure(const BodyDev &B, const double (&x)[D], double fastd2, double &d, double (&n)[D], double (&V)[D]) {
+__device__ __forceinline__ void body_measure(const BodyDev &BB, const double (&x)[D], double fastd2, double &d, double (&n)[D], double (&V)[D]) {
     double xi[D], gx[D];
-    body_map<D>(B, x, xi);
 #pragma unroll
     for (int a = 0; a < D; ++a) { n[a] = 0; V[a] = 0; }
-    d = body_sdf<D>(B, xi, gx, false);
+    int act; double sgn;
+    d = body_sdf<D>(BB, x, act, sgn);
     if (d * d > fastd2) return;                       // :118
-    d = body_sdf<D>(B, xi, gx, true);
+    const LeafDev &B = BB.leaf[act];
+    body_map<D>(B, x, xi);
+    d = sgn * leaf_sdf<D>(B, xi, gx, true);
     double g[D];
     bool nan = false;
 #pragma unroll
@@ -100,6 +133,7 @@ __device__ __forceinline__ void body_measure(const BodyDev &B, const double (&x)
 #pragma unroll
             for (int a = 0; a < D; ++a) s += B.A[3 * a + c] * gx[a];
         }
+        s *= sgn;
         g[c] = s;
         nan = nan || (s != s);
     }
@@ -158,10 +192,9 @@ __global__ __launch_bounds__(256) void k_measure_rows(G g, BodyDev B, T *sigma, 
     const bool inside_row = j >= 1 && j <= g.n[1] - 2 && (D < 3 || (kg >= 1 && kg <= g.nzg - 2));
     if (inside_row) {
         for (int i = 1 + lane; i <= g.n[0] - 2; i += 64) {
-            double x[D], xi[D], gg[D];
+            double x[D];
             cell_loc<D>(g, i, j, k, x);
-            body_map<D>(B, x, xi);
-            const T d = (T)body_sdf<D>(B, xi, gg, false);
+            const T d = (T)body_sdf<D>(B, x);
             sigma[g.at(i, j, k)] = d;                                  // Body.jl:34
             const bool band = d * d < d2;                              // :35 (in T)
             cnt += band ? 1 : 0;

@@ -682,15 +682,15 @@ def measure_flow(a: Flow, body, t=0.0, eps=1, geometry="device") -> None:
         return
     dims = tuple(n - 2 for n in a.N)
     a._band_cells = None
-    if geometry == "device" and isinstance(body, B.ParametricBody):
+    if geometry == "device" and B.is_native(body):
         # closed-form family + affine map: the whole measure! (fill loop, both BC! calls, halos, row flags) runs as
         # hand-written kernels (csrc/wl_measure.h); only rows holding body cells now or before are rewritten
         L = _lib.lib()
         desc = body.native_desc(t, a.D)
         nband = C.c_int64()
-        check(L.wl_measure_rows(a._h, C.byref(desc), float(eps), C.byref(nband)))
+        check(L.wl_measure_rows(a._h, desc, float(eps), C.byref(nband)))
         cand = torch.empty(max(1, nband.value), dtype=torch.int64, device=a.device)
-        check(L.wl_measure_fill(a._h, C.byref(desc), float(eps), C.c_void_p(cand.data_ptr())))
+        check(L.wl_measure_fill(a._h, desc, float(eps), C.c_void_p(cand.data_ptr())))
         a._band_cells = (float(t), cand[:nband.value])
         return
     if geometry == "device":
@@ -830,7 +830,7 @@ def _ensure_band(sim: Simulation) -> None:
         return
     dims = tuple(n - 2 for n in sim.flow.N)
     bc = getattr(sim.flow, "_band_cells", None)
-    if bc is not None and sim.geometry == "device" and isinstance(sim.body, B.ParametricBody):
+    if bc is not None and sim.geometry == "device" and B.is_native(sim.body):
         cand = bc[1]
         if sim.slab is not None:                       # owned interior planes only (the force is all-reduced)
             kk = cand // int(sim.flow.N[0] * sim.flow.N[1])
@@ -839,7 +839,7 @@ def _ensure_band(sim: Simulation) -> None:
         desc = sim.body.native_desc(t, sim.flow.D)
         nds = torch.empty((cand.numel(), sim.flow.D), dtype=torch.float64, device=cand.device)
         g = _grid_of(sim.flow.p, sim.flow.D)
-        check(_lib.lib().wl_body_nds(C.byref(g), C.byref(desc), C.c_void_p(cand.data_ptr()), cand.numel(), C.c_void_p(nds.data_ptr())))
+        check(_lib.lib().wl_body_nds(C.byref(g), desc, C.c_void_p(cand.data_ptr()), cand.numel(), C.c_void_p(nds.data_ptr())))
         keep = (nds != 0).any(1)
         sim._band = (t,) + band_to_device_t(sim.flow.p, cand[keep], nds[keep])
         return
