@@ -40,6 +40,38 @@ def test_argument_validation_without_gpu():
         _lib.check(_lib.WL_E_LEVELS)
 
 
+def test_new_entry_points_validate_without_gpu():
+    """ABI v5 additions reject bad calls before touching the device: the mailbox needs a communicator and a POSIX name,
+    the log reader and L-inf need their outputs, composite bodies are bounded."""
+    L = _lib.lib()
+    assert L.wl_comm_mailbox(b"/wlhip-test", 1) == _lib.WL_E_STATE and b"communicator" in L.wl_last_error()
+    on = C.c_int(7)
+    assert L.wl_comm_mailbox_active(C.byref(on)) == 0 and on.value == 0
+    assert L.wl_comm_mailbox_off() == 0
+    v = (C.c_int64 * 6)(*[9] * 6)
+    assert L.wl_prof_comm(v) == 0 and list(v) == [0] * 6
+    assert L.wl_prof_reset_comm() == 0
+    assert L.wl_mg_log(None, 1) != 0 and L.wl_mg_log_read(None, None, 0, None) != 0
+    assert L.wl_mg_Linf(None, 0, None) != 0
+    assert L.wl_set_option(31, 0) == 0 and L.wl_set_option(32, 0) != 0
+    # body descriptors: family / composite checks happen on the host
+    bd = (_lib.BodyDesc * 2)()
+    bd[0].family, bd[0].count = 9, 1
+    nb = C.c_int64()
+    assert L.wl_measure_rows(None, bd, 1.0, C.byref(nb)) != 0          # null flow handle
+    g = _lib.Grid()
+    g.D = 3
+    g.n[:] = [8, 8, 8]
+    g.s[:] = [1, 8, 64]
+    g.sc = 512
+    assert L.wl_body_nds(C.byref(g), bd, None, 4, None) != 0 and b"family" in L.wl_last_error()
+    bd[0].family, bd[0].count = _lib.WL_BODY_SPHERE, _lib.WL_BODY_MAXLEAF + 1
+    assert L.wl_body_nds(C.byref(g), bd, None, 4, None) != 0 and b"WL_BODY_MAXLEAF" in L.wl_last_error()
+    bd[0].count = 2
+    bd[1].family, bd[1].op = _lib.WL_BODY_CYLINDER, 5
+    assert L.wl_body_nds(C.byref(g), bd, None, 4, None) != 0 and b"operation" in L.wl_last_error()
+
+
 def test_no_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():

@@ -15,7 +15,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "wlhip.h")
 _lib = None
 
 WL_F32, WL_F64 = 0, 1
-WL_E_LEVELS = 10002
+WL_E_ARG, WL_E_LEVELS, WL_E_NOGPU, WL_E_STATE = 10001, 10002, 10003, 10004
 
 
 class WlError(RuntimeError):
