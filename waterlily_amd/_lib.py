@@ -10,7 +10,7 @@ import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwlhip.so")
+LIB_PATH = os.environ.get("WLHIP_LIB") or os.path.join(_HERE, "libwlhip.so")   # (WLHIP_LIB: an alternative build, A/B measurements)
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "wlhip.h")
 _lib = None
 

@@ -65,6 +65,9 @@ template <class T> struct VecA {   // array view of a 16-B vector
 };
 
 constexpr int S7_BY = 4;   // wavefronts per workgroup of the vector kernels
+#ifndef WL_ROWVEC_DEPTH
+#define WL_ROWVEC_DEPTH 1  // planes the streaming kernel k_rowvec requests ahead of the one it works on (1 or 2)
+#endif
 
 // Device-side gate and scalars of a solver kernel, read ONCE per thread before its z loop (uniform addresses): inside
 // the loop they would be re-loaded every plane (the stores in between may alias them as far as the compiler knows),
@@ -490,23 +493,48 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, LD ld, ST st, const T *rowc
     if (run && i <= g.n[0] - 2 && j <= g.n[1] - 2 && k0 < k1) {
         const long col = (long)i + g.s[1] * (long)j;
         const long n1 = g.n[1];
+        using Dat = decltype(ld(col, j, k0, pre));
+        // (two copies of the consumer: in a coefficient-uniform row no instruction can load iD -- see RowKU)
+        auto consume = [&](int k, const Dat &cur, const RowK<T> &rkc) {
+            if (RK && rkc.uni()) st(col + g.s[2] * k, i, j, k, cur, RowKU<T>(rkc), acc, pre);
+            else st(col + g.s[2] * k, i, j, k, cur, rkc, acc, pre);
+        };
+        auto rkl = [&](int k) { return RK ? rowk_load<T>(rowc, j + n1 * k) : rowk_none<T>(); };
+#if WL_ROWVEC_DEPTH == 2
+        // THREE operand sets rotate (loop unrolled by three): the operands of plane k+2 are requested before plane k is
+        // worked on -- two planes of every stream in flight per wavefront.  The streaming kernels are short of bytes in flight,
+        // not of issue slots or registers (rocprofv3 SQ counters, DESIGN.md section 4: 50-70 % of their wave cycles parked on
+        // s_waitcnt at 16-74 VGPRs), and what they reach follows what they keep in flight per CU: 32 KB -> 5.1 TB/s
+        // (scale), 48 KB -> 5.6 (pcg update), 96 KB -> 5.9 (pcg direction).
+        const int kl = k1 - 1;
+        Dat d0 = ld(col + g.s[2] * k0, j, k0, pre), d1 = ld(col + g.s[2] * min(k0 + 1, kl), j, min(k0 + 1, kl), pre), d2;
+        RowK<T> r0 = rkl(k0), r1 = rkl(min(k0 + 1, kl)), r2 = rowk_none<T>();
+        auto step = [&](int k, const Dat &cur, const RowK<T> &rkc, Dat &nxt, RowK<T> &rkn) {
+            const int kn = min(k + 2, kl);
+            nxt = ld(col + g.s[2] * kn, j, kn, pre);
+            rkn = rkl(kn);
+            consume(k, cur, rkc);
+        };
+        for (int k = k0; k < k1; k += 3) {
+            step(k, d0, r0, d2, r2);
+            if (k + 1 < k1) step(k + 1, d1, r1, d0, r0);
+            if (k + 2 < k1) step(k + 2, d2, r2, d1, r1);
+        }
+#else
         // two operand sets alternate (loop unrolled by two): a set is never copied while its loads are outstanding
-        auto dA = ld(col + g.s[2] * k0, j, k0, pre);
-        using Dat = decltype(dA);
-        Dat dB;
-        RowK<T> rkA = RK ? rowk_load<T>(rowc, j + n1 * k0) : rowk_none<T>(), rkB = rowk_none<T>();
+        Dat dA = ld(col + g.s[2] * k0, j, k0, pre), dB;
+        RowK<T> rkA = rkl(k0), rkB = rowk_none<T>();
         auto step = [&](int k, const Dat &cur, const RowK<T> &rkc, Dat &nxt, RowK<T> &rkn) {
             const int kn = min(k + 1, k1 - 1);
             nxt = ld(col + g.s[2] * kn, j, kn, pre);
-            rkn = RK ? rowk_load<T>(rowc, j + n1 * kn) : rowk_none<T>();
-            // (two copies of the consumer: in a coefficient-uniform row no instruction can load iD -- see RowKU)
-            if (RK && rkc.uni()) st(col + g.s[2] * k, i, j, k, cur, RowKU<T>(rkc), acc, pre);
-            else st(col + g.s[2] * k, i, j, k, cur, rkc, acc, pre);
+            rkn = rkl(kn);
+            consume(k, cur, rkc);
         };
         for (int k = k0; k < k1; k += 2) {
             step(k, dA, rkA, dB, rkB);
             if (k + 1 < k1) step(k + 1, dB, rkB, dA, rkA);
         }
+#endif
     }
     if (NRED > 0) {
         block_red<(NRED > 0 ? NRED : 1), 4>(acc, OP);
