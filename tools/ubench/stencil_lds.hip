@@ -46,7 +46,8 @@ struct Geo { int n; long sy, sz; int ntx, nty, clen; };
 
 // (b) register-window 7-point sweep: what the product's kernel does (1 plane ahead, R = 2 rows per thread, halo rows and
 // edge cells loaded from global), coefficient 1 everywhere: Ae = -6 e + sum of 6 neighbours; acc += Ae * e
-__global__ __launch_bounds__(256) void k_regwin(const float *e, Geo g, double *out) {
+template <bool STORE, bool RC>
+__global__ __launch_bounds__(256) void k_regwin(const float *e, Geo g, double *out, float *z, const float *rowc) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tpp = g.ntx * g.nty;
     const int ch = blockIdx.x / tpp, pt = blockIdx.x - ch * tpp;
@@ -61,8 +62,15 @@ __global__ __launch_bounds__(256) void k_regwin(const float *e, Geo g, double *o
     f4 hlo = LD(col - g.sy + g.sz * k0), hhi = LD(col + 2 * g.sy + g.sz * k0);
     float lf[2] = {0, 0}, rg[2] = {0, 0};
     for (int q = 0; q < 2; ++q) { if (lane == 0) lf[q] = e[col + q * g.sy + g.sz * k0 - 1]; if (lane == 63) rg[q] = e[col + q * g.sy + g.sz * k0 + 4]; }
+    typedef float rc8 __attribute__((ext_vector_type(8)));
+    typedef const __attribute__((address_space(4))) rc8 *cptr;
+    const int jbu = __builtin_amdgcn_readfirstlane(jb);
+    rc8 rk[2] = {rc8{1, 0, 0, 0, 0, 0, 0, 0}, rc8{1, 0, 0, 0, 0, 0, 0, 0}};
+    if (RC) for (int q = 0; q < 2; ++q) rk[q] = *(cptr)(rowc + 8 * ((long)(jbu + q) + (long)(g.n + 2) * k0));
     for (int k = k0; k < k1; ++k) {
         const int kn = min(k + 1, k1 - 1);
+        rc8 rkn[2] = {rk[0], rk[1]};
+        if (RC) for (int q = 0; q < 2; ++q) rkn[q] = *(cptr)(rowc + 8 * ((long)(jbu + q) + (long)(g.n + 2) * kn));
         f4 nown[2] = {LD(col + g.sz * (kn + 1)), LD(col + g.sy + g.sz * (kn + 1))};
         f4 nlo = LD(col - g.sy + g.sz * kn), nhi = LD(col + 2 * g.sy + g.sz * kn);
         float nlf[2] = {0, 0}, nrg[2] = {0, 0};
@@ -75,9 +83,21 @@ __global__ __launch_bounds__(256) void k_regwin(const float *e, Geo g, double *o
             const float xm[4] = {left, c.x, c.y, c.z}, xp[4] = {c.y, c.z, c.w, right};
             const float cc[4] = {c.x, c.y, c.z, c.w}, a1[4] = {ym.x, ym.y, ym.z, ym.w}, a2[4] = {yp.x, yp.y, yp.z, yp.w};
             const float a3[4] = {zm.x, zm.y, zm.z, zm.w}, a4[4] = {zp.x, zp.y, zp.z, zp.w};
-            for (int v = 0; v < 4; ++v) { const float ae = -6.f * cc[v] + xm[v] + xp[v] + a1[v] + a2[v] + a3[v] + a4[v]; acc += (double)ae * (double)cc[v]; }
+            float cf = 1.f;
+            if (RC) {
+                cf = rk[q][0];
+                if (!(cf == cf)) cf = e[col + q * g.sy + g.sz * k];   // "not uniform": a load behind a rarely taken branch (never here)
+            }
+            f4 aev;
+            float *ap = reinterpret_cast<float *>(&aev);
+            for (int v = 0; v < 4; ++v) {
+                const float ae = cf * (-6.f * cc[v] + xm[v] + xp[v] + a1[v] + a2[v] + a3[v] + a4[v]);
+                ap[v] = ae;
+                acc += (double)ae * (double)cc[v];
+            }
+            if (STORE) *reinterpret_cast<f4 *>(z + col + q * g.sy + g.sz * k) = aev;
         }
-        for (int q = 0; q < 2; ++q) { em[q] = ec[q]; ec[q] = own[q]; own[q] = nown[q]; lf[q] = nlf[q]; rg[q] = nrg[q]; }
+        for (int q = 0; q < 2; ++q) { em[q] = ec[q]; ec[q] = own[q]; own[q] = nown[q]; lf[q] = nlf[q]; rg[q] = nrg[q]; rk[q] = rkn[q]; }
         hlo = nlo; hhi = nhi;
     }
     block_out(acc, out);
@@ -88,8 +108,11 @@ __global__ __launch_bounds__(256) void k_regwin(const float *e, Geo g, double *o
 // the 20 x-edge cells of a plane arrive by ONE global_load_lds_dword (per-lane source addresses, contiguous LDS image)
 template <int NS> __global__ __launch_bounds__(256) void k_ldsring(const float *e, Geo g, double *out) {
     constexpr int TY = 8, ROWS = TY + 2;
-    __shared__ __attribute__((aligned(16))) float ring[NS][ROWS][256];
-    __shared__ __attribute__((aligned(16))) float edge[NS][64];
+    // ONE __shared__ object for everything (cdna_hip_programming.md: a second object beside a glds staging array can make hipcc
+    // drain the DMA queue -- s_waitcnt vmcnt(0) -- before every ds_read): [NS][ROWS][256] ring, [NS][64] edge cells, 16 doubles
+    __shared__ __attribute__((aligned(16))) float smem[NS * ROWS * 256 + NS * 64 + 32];
+    auto ring = [&](int s_, int r_) -> float * { return smem + ((long)s_ * ROWS + r_) * 256; };
+    float *edge0 = smem + NS * ROWS * 256;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tpp = g.ntx * g.nty;
     const int ch = blockIdx.x / tpp, pt = blockIdx.x - ch * tpp;
@@ -102,12 +125,12 @@ template <int NS> __global__ __launch_bounds__(256) void k_ldsring(const float *
         const int pc = min(max(p, 0), g.n + 1);
         for (int r = wv; r < ROWS; r += 4)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(e + base + g.sy * r + g.sz * pc),
-                                             (__attribute__((address_space(3))) void *)&ring[s][r][0], 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)ring(s, r), 16, 0, 0);
         if (wv == 3) {   // lane l < 20: row l>>1, side l&1
             const int r = min(lane >> 1, ROWS - 1), side = lane & 1;
             const long o = (long)i0 + (side ? 256 : -1) + g.sy * (j0 - 1 + r) + g.sz * pc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(e + o),
-                                             (__attribute__((address_space(3))) void *)&edge[s][0], 4, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(edge0 + s * 64), 4, 0, 0);
         }
     };
     // per-wavefront number of load instructions per plane: rows {3,3,2,2} + edge on wavefront 3 -> {3,3,2,3}
@@ -130,17 +153,19 @@ template <int NS> __global__ __launch_bounds__(256) void k_ldsring(const float *
     };
     wait_keep(NS - 3);           // outstanding may be: planes k0+1 .. k0+NS-3  (NS-3 planes)
     __builtin_amdgcn_s_barrier();
-    auto RD = [&](int s, int r) { return *reinterpret_cast<const f4 *>(&ring[s][r][lane * 4]); };
+    auto RD = [&](int s_, int r_) { return *reinterpret_cast<const f4 *>(ring(s_, r_) + lane * 4); };
     const int r0 = 1 + 2 * wv;   // first own row of this wavefront in the tile
     f4 em[2] = {RD((k0 - 1) % NS, r0), RD((k0 - 1) % NS, r0 + 1)}, ec[2] = {RD(k0 % NS, r0), RD(k0 % NS, r0 + 1)};
     for (int k = k0; k < k1; ++k) {
-        // plane k+1 must have landed: keep planes k+2 .. k+NS-3+... in flight.  In flight now: k+1 .. k+NS-3 -> keep NS-4... then issue
-        wait_keep(NS - 4 >= 0 ? NS - 4 : 0);
-        __builtin_amdgcn_s_barrier();            // all wavefronts' rows of plane k+1 are in LDS; slot of plane k-1 is free
-        issue(k + NS - 2);                       // into the slot of plane k-2+NS = (k-2)%NS ... see note below
+        // slot (k-2)%NS is free since the barrier of iteration k-1: plane k+NS-2 goes there, BEFORE the wait (longer flight).
+        // In flight now: planes k+1 .. k+NS-2; plane k+1 must have landed -> keep NS-3 planes' loads outstanding.
+        issue(k + NS - 2);
+        wait_keep(NS - 3);
+        __builtin_amdgcn_s_barrier();            // every wavefront's rows of plane k+1 are in LDS
         const int sc = k % NS, sp = (k + 1) % NS;
         const f4 own0 = RD(sp, r0), own1 = RD(sp, r0 + 1), hlo = RD(sc, r0 - 1), hhi = RD(sc, r0 + 2);
-        const float el0 = edge[sc][2 * r0], er0 = edge[sc][2 * r0 + 1], el1 = edge[sc][2 * r0 + 2], er1 = edge[sc][2 * r0 + 3];
+        const float *ed = edge0 + sc * 64;
+        const float el0 = ed[2 * r0], er0 = ed[2 * r0 + 1], el1 = ed[2 * r0 + 2], er1 = ed[2 * r0 + 3];
         const f4 own[2] = {own0, own1};
         const float lf[2] = {el0, el1}, rg[2] = {er0, er1};
         for (int q = 0; q < 2; ++q) {
@@ -156,7 +181,14 @@ template <int NS> __global__ __launch_bounds__(256) void k_ldsring(const float *
         for (int q = 0; q < 2; ++q) { em[q] = ec[q]; ec[q] = own[q]; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    block_out(acc, out);
+    {   // block reduction in the same shared object
+        double *sm = reinterpret_cast<double *>(smem + NS * ROWS * 256 + NS * 64);
+        acc = wave_sum(acc);
+        __syncthreads();
+        if (lane == 0) sm[wv] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) out[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+    }
 }
 
 int main(int argc, char **argv) {
@@ -198,7 +230,21 @@ int main(int argc, char **argv) {
     run("flat read, 2 loads in flight", [&] { hipLaunchKernelGGL(k_flat<2>, dim3(8192), dim3(256), 0, 0, (const f4 *)(e + 1), nv - 8, out); }, (double)nv * 16);
     run("flat read, 4 loads in flight", [&] { hipLaunchKernelGGL(k_flat<4>, dim3(8192), dim3(256), 0, 0, (const f4 *)(e + 1), nv - 8, out); }, (double)nv * 16);
     CK(hipMemset(out, 0, sizeof(double) * 65536));
-    run("7-point, register window (R=2)", [&] { hipLaunchKernelGGL(k_regwin, dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out); }, arr);
+    float *zb, *rowc;
+    CK(hipMalloc(&zb, total * sizeof(float)));
+    CK(hipMalloc(&rowc, sizeof(float) * 8 * (n + 2) * (n + 2)));
+    { std::vector<float> hr((size_t)8 * (n + 2) * (n + 2), 1.0f); CK(hipMemcpy(rowc, hr.data(), hr.size() * 4, hipMemcpyHostToDevice)); }
+    float *z = zb + lead;
+    run("7-point, register window (R=2)", [&] { hipLaunchKernelGGL((k_regwin<false, false>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, arr);
+    run("  + row constants (s_load x8)", [&] { hipLaunchKernelGGL((k_regwin<false, true>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, arr);
+    run("  + store z", [&] { hipLaunchKernelGGL((k_regwin<true, false>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, 2 * arr);
+    run("  + store z + row constants", [&] { hipLaunchKernelGGL((k_regwin<true, true>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, 2 * arr);
+    for (int cl : {8, 32, 64}) {
+        Geo g2 = g; g2.clen = cl;
+        const int nb2 = g.ntx * g.nty * ((n + cl - 1) / cl);
+        char nm[64]; snprintf(nm, sizeof nm, "  + store z, chunks of %d planes", cl);
+        run(nm, [&] { hipLaunchKernelGGL((k_regwin<true, false>), dim3(nb2), dim3(256), 0, 0, (const float *)e, g2, out, z, (const float *)rowc); }, 2 * arr);
+    }
     CK(hipMemset(out, 0, sizeof(double) * 65536));
     run("7-point, LDS ring NS=4 (glds)", [&] { hipLaunchKernelGGL(k_ldsring<4>, dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out); }, arr);
     CK(hipMemset(out, 0, sizeof(double) * 65536));
