@@ -46,11 +46,13 @@ struct Geo { int n; long sy, sz; int ntx, nty, clen; };
 
 // (b) register-window 7-point sweep: what the product's kernel does (1 plane ahead, R = 2 rows per thread, halo rows and
 // edge cells loaded from global), coefficient 1 everywhere: Ae = -6 e + sum of 6 neighbours; acc += Ae * e
-template <bool STORE, bool RC>
+template <bool STORE, bool RC, int ARITH = 0, bool XCD = false>
 __global__ __launch_bounds__(256) void k_regwin(const float *e, Geo g, double *out, float *z, const float *rowc) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tpp = g.ntx * g.nty;
-    const int ch = blockIdx.x / tpp, pt = blockIdx.x - ch * tpp;
+    const int nb_ = gridDim.x, b_ = blockIdx.x;
+    const int lb_ = XCD ? ((b_ & 7) * (nb_ >> 3) + (b_ >> 3)) : b_;   // XCD: every XCD gets a CONTIGUOUS range of tiles (the product's mapping)
+    const int ch = lb_ / tpp, pt = lb_ - ch * tpp;
     const int i = 1 + (pt % g.ntx) * 256 + lane * 4, jb = 1 + (pt / g.ntx) * 8 + wv * 2;
     const int k0 = 1 + ch * g.clen, k1 = min(g.n + 1, k0 + g.clen);
     double acc = 0;
@@ -91,7 +93,23 @@ __global__ __launch_bounds__(256) void k_regwin(const float *e, Geo g, double *o
             f4 aev;
             float *ap = reinterpret_cast<float *>(&aev);
             for (int v = 0; v < 4; ++v) {
-                const float ae = cf * (-6.f * cc[v] + xm[v] + xp[v] + a1[v] + a2[v] + a3[v] + a4[v]);
+                float ae;
+                if (ARITH == 1) {        // the product's sequence: diagonal from the six faces, seven products, separately rounded
+                    const float c = cf;
+                    float dg = 0;
+                    dg -= (c + c); dg -= (c + c); dg -= (c + c);
+                    float s_ = cc[v] * dg;
+                    s_ += xm[v] * c + xp[v] * c;
+                    s_ += a1[v] * c + a2[v] * c;
+                    s_ += a3[v] * c + a4[v] * c;
+                    ae = s_;
+                } else if (ARITH == 2) { // unit coefficients: the same values with the products by 1 dropped
+                    float s_ = cc[v] * -6.f;
+                    s_ += xm[v] + xp[v];
+                    s_ += a1[v] + a2[v];
+                    s_ += a3[v] + a4[v];
+                    ae = s_;
+                } else ae = cf * (-6.f * cc[v] + xm[v] + xp[v] + a1[v] + a2[v] + a3[v] + a4[v]);
                 ap[v] = ae;
                 acc += (double)ae * (double)cc[v];
             }
@@ -208,15 +226,34 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&out, sizeof(double) * 65536));
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    // FLUSH=1 in the environment: a 2 GB fill of another buffer runs before every timed launch (what a kernel meets inside a
+    // time step: nothing of its operands left in the 256 MB Infinity Cache by the launch before it); each launch timed alone
+    const bool flush = getenv("FLUSH") && getenv("FLUSH")[0] == '1';
+    float *scratch = nullptr;
+    const size_t nscr = 512ull << 20;   // floats = 2 GB
+    if (flush) CK(hipMalloc(&scratch, nscr * sizeof(float)));
     auto run = [&](const char *name, auto launch, double bytes) {
         launch();
         CK(hipDeviceSynchronize());
-        CK(hipEventRecord(a));
-        for (int r = 0; r < reps; ++r) launch();
-        CK(hipEventRecord(b));
-        CK(hipEventSynchronize(b));
-        float ms;
-        CK(hipEventElapsedTime(&ms, a, b));
+        float ms = 0;
+        if (flush) {
+            for (int r = 0; r < reps; ++r) {
+                CK(hipMemsetAsync(scratch, r & 0xff, nscr * sizeof(float), 0));
+                CK(hipEventRecord(a));
+                launch();
+                CK(hipEventRecord(b));
+                CK(hipEventSynchronize(b));
+                float t;
+                CK(hipEventElapsedTime(&t, a, b));
+                ms += t;
+            }
+        } else {
+            CK(hipEventRecord(a));
+            for (int r = 0; r < reps; ++r) launch();
+            CK(hipEventRecord(b));
+            CK(hipEventSynchronize(b));
+            CK(hipEventElapsedTime(&ms, a, b));
+        }
         std::vector<double> ho(65536);
         CK(hipMemcpy(ho.data(), out, sizeof(double) * 65536, hipMemcpyDeviceToHost));
         double sum = 0;
@@ -238,6 +275,10 @@ int main(int argc, char **argv) {
     run("7-point, register window (R=2)", [&] { hipLaunchKernelGGL((k_regwin<false, false>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, arr);
     run("  + row constants (s_load x8)", [&] { hipLaunchKernelGGL((k_regwin<false, true>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, arr);
     run("  + store z", [&] { hipLaunchKernelGGL((k_regwin<true, false>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, 2 * arr);
+    run("  + store z, XCD-contiguous tile map", [&] { hipLaunchKernelGGL((k_regwin<true, false, 0, true>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, 2 * arr);
+    run("  no store,  XCD-contiguous tile map", [&] { hipLaunchKernelGGL((k_regwin<false, false, 0, true>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, arr);
+    run("  + store z, product arithmetic", [&] { hipLaunchKernelGGL((k_regwin<true, false, 1>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, 2 * arr);
+    run("  + store z, unit-coefficient form", [&] { hipLaunchKernelGGL((k_regwin<true, false, 2>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, 2 * arr);
     run("  + store z + row constants", [&] { hipLaunchKernelGGL((k_regwin<true, true>), dim3(nblk), dim3(256), 0, 0, (const float *)e, g, out, z, (const float *)rowc); }, 2 * arr);
     for (int cl : {8, 32, 64}) {
         Geo g2 = g; g2.clen = cl;
