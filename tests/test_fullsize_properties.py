@@ -194,7 +194,8 @@ def test_traffic_saving_switches_do_not_change_a_bit(S, case):
     """The kernels that move fewer bytes than the dense algorithm -- row constants instead of L/iD in coefficient-
     uniform rows (option 9), x += alpha*eps deferred to the direction kernel (8), z' = r*iD recomputed instead of
     stored (13), z = A*eps formed a second time by the update kernel instead of stored (19), body-free rows in BDIM! (3), the chained x/=dt ; x*=dt' pass (14), the shared-flux conv_diff! kernel (18, 20), its x-ghost launch (21), div(u)
-    formed inside residual! (22), the x planes of BC! written by the producing kernel (23) -- evaluate the same expressions: three steps of the case give
+    formed inside residual! (22), the x planes of BC! written by the producing kernel (23), consecutive kernels sweeping in
+    opposite directions (30) -- evaluate the same expressions: three steps of the case give
     bit-identical u and p with all of them off."""
     dims, T, kind = case
     if int(np.prod(dims)) > 512 ** 3:
@@ -205,7 +206,7 @@ def test_traffic_saving_switches_do_not_change_a_bit(S, case):
     # everything downstream (tools/whichswitch.py) -- so there these three are compared on their own, to rounding, and the
     # other switches (none of which regroups a sum) bit for bit.
     f64 = np.dtype(T) == np.float64
-    keys = (3, 9, 14, 18, 20, 21, 22, 23) + (() if f64 else (8, 13, 19))
+    keys = (3, 9, 14, 18, 20, 21, 22, 23, 30) + (() if f64 else (8, 13, 19))
     regroup = (8, 13, 19)
 
     def run(off):

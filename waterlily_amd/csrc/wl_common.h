@@ -70,12 +70,13 @@ struct Mailbox {
 
 struct Ctx {
     Mailbox *mbox = nullptr;
-    int opt[32] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 1, 1, 1, 1, 1024, 0, 40000, 0, 16, 0, 0, 0};   // wl_set_option
+    int opt[32] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 1, 1, 1, 1, 1024, 0, 40000, 0, 16, 0, 1, 0};   // wl_set_option
     Comm *comm = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
     int64_t launches[WL_K_COUNT] = {0};
     int64_t cells[WL_K_COUNT] = {0};
+    int sweep = 0;                     // direction of the last marching launch (sweep_rev)
     int prof_class = -1;
     int64_t prof_min_cells = 0;
     std::vector<TimedEvt> evts;
@@ -536,6 +537,26 @@ inline int halo_end() {
     c.halo_pending = false;
     WL_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
     return 0;
+}
+
+// Consecutive marching kernels sweep in OPPOSITE directions (wl_set_option(30)): each XCD keeps its range of tiles -- its slab
+// of the z axis, the same for every kernel -- but starts where the kernel before it stopped, on the lines that kernel has
+// just read or written and that still sit in the XCD's L2 and in the 256 MB Infinity Cache (a 512^3 Float32 array is
+// 537 MB: without the reversal every kernel begins on the lines that were evicted first).  The tile a workgroup takes
+// changes, the slot its reduction partial goes to stays that tile's: sums and fields are bit-identical either way.
+inline int sweep_rev() {
+    Ctx &c = ctx();
+    if (!c.opt[30]) return 0;
+    c.sweep ^= 1;
+    return c.sweep;
+}
+// logical tile of physical workgroup b, and the slot of that tile's partial (= the workgroup that takes it when rev = 0)
+__device__ __forceinline__ void tile_of(int b, int nblk, int rev, int &lb, int &pslot) {
+    if (nblk & 7) { lb = b; pslot = b; return; }
+    const int per = nblk >> 3, q = b >> 3;
+    const int qq = rev ? per - 1 - q : q;
+    lb = (b & 7) * per + qq;
+    pslot = (qq << 3) | (b & 7);
 }
 
 // ---- neighbour-lane exchange by DPP wave shifts (gfx9 family: wave_shr:1 / wave_shl:1): one VALU move per 32 bits,

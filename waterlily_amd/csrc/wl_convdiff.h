@@ -446,12 +446,14 @@ __device__ __forceinline__ void convdiff3s_tile(CdsShared<T, BY> &S_, const G &g
 template <class T, bool FUSE, bool COPY, int BY>
 __global__ __launch_bounds__(CD_BX *BY) void k_convdiff3s(G g, T *__restrict__ r, const T *__restrict__ u, T nu, const T *u0, T *u0out,
                                                          const T *__restrict__ V, T dt, double a0, double a1, double a2, bool has_acc,
-                                                         int ntx, int tpp, int nblk, int clen, int jbase, int klo, int khi, int ntile) {
+                                                         int ntx, int tpp, int nblk, int clen, int jbase, int klo, int khi, int ntile, int rev) {
     // (dynamic LDS: CdsShared<double, 8> is 86.6 KB -- more than the 64 KB a static __shared__ object may take)
     extern __shared__ __attribute__((aligned(16))) unsigned char cds_raw[];
     CdsShared<T, BY> &S_ = *reinterpret_cast<CdsShared<T, BY> *>(cds_raw);
     const int b = blockIdx.x;
-    const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);  // XCD-contiguous logical id
+    int lb, pslot;
+    tile_of(b, nblk, rev, lb, pslot);                                  // XCD-contiguous logical id
+    (void)pslot;
     const int ch = lb / tpp, pt = lb - ch * tpp;
     const int n0 = g.n[0], n1 = g.n[1];
     const int i0 = 1 + CD_BX * (pt % ntx), j0 = jbase + BY * (pt / ntx);   // jbase: first row of this launch's tile rows
@@ -530,6 +532,7 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
     const int nown = khi - klo + 1;
     // 8-row tiles (Float32: 43 KB of LDS per workgroup; Float64: 86.6 KB, optional), 4-row tiles for the rows that do not
     // fill one
+    const int rev = sweep_rev();
     auto launch = [&](auto BYc, int jbase, int ntr) -> int {   // ntr tile rows of BY rows starting at row jbase
         constexpr int BY = decltype(BYc)::value;
         if (ntr <= 0) return 0;
@@ -551,7 +554,7 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
             }
         }
         hipLaunchKernelGGL((k_convdiff3s<T, FUSE, COPY, BY>), dim3(nblk), dim3(CD_BX * BY), lds, ctx().stream, g, r, u, (T)nu_, u0, u0out, V,
-                           (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen, jbase, klo, khi, ntile);
+                           (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen, jbase, klo, khi, ntile, rev);
         return (int)hipGetLastError();
     };
     const int rows = nty * CD_BY, jb0 = tlo * CD_BY;

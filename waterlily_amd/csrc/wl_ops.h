@@ -646,7 +646,7 @@ template <class T> __device__ __forceinline__ T scale_one(T x, const ScaleOp &o)
     return o.divide ? x / (T)o.s : x * (T)o.s;
 }
 template <class T>
-__global__ __launch_bounds__(256) void k_scale_flat(T *a, long n, long head, ScaleOp o1, ScaleOp o2, bool two) {
+__global__ __launch_bounds__(256) void k_scale_flat(T *a, long n, long head, ScaleOp o1, ScaleOp o2, bool two, int rev) {
     constexpr int V = 16 / sizeof(T);
     auto one = [&](T x) -> T {
         const T y = scale_one<T>(x, o1);
@@ -654,7 +654,8 @@ __global__ __launch_bounds__(256) void k_scale_flat(T *a, long n, long head, Sca
     };
     const long nv = (n - head) / V;                 // whole aligned vectors after the unaligned head
     const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
-    for (long q = t0; q < nv; q += nt) {
+    for (long q0 = t0; q0 < nv; q0 += nt) {
+        const long q = rev ? nv - 1 - q0 : q0;            // (alternating sweep direction: see sweep_rev)
         VecA<T> v = VecA<T>::load(a + head + q * V);
 #pragma unroll
         for (int e = 0; e < V; ++e) v.v[e] = one(v.v[e]);
@@ -677,7 +678,7 @@ int op_scale_all(const G &g, T *a, double s, bool divide, bool dbl, const ScaleO
     if (nb < 1) nb = 1;
     Prof p(WL_K_SCALE, r_whole(g).count());
     const ScaleOp o1{s, divide, dbl};
-    hipLaunchKernelGGL((k_scale_flat<T>), dim3((unsigned)nb), dim3(256), 0, ctx().stream, a, n, head, o1, then ? *then : o1, then != nullptr);
+    hipLaunchKernelGGL((k_scale_flat<T>), dim3((unsigned)nb), dim3(256), 0, ctx().stream, a, n, head, o1, then ? *then : o1, then != nullptr, sweep_rev());
     return (int)hipGetLastError();
 }
 
@@ -744,12 +745,14 @@ _Pragma("unroll")
 template <class T>
 __global__ __launch_bounds__(64 * S7_BY) void k_correct3(G g, T *__restrict__ u, const T *__restrict__ L, const T *__restrict__ x,
                                                   const T *__restrict__ rowc, int ntx, int tpp, int nblk, int clen, int klo, int khi,
-                                                  XBc<T> xb) {
+                                                  XBc<T> xb, int rev) {
     constexpr int V = Vec16<T>::V;
     using VA = VecA<T>;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x;
-    const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);
+    int lb, pslot;
+    tile_of(b, nblk, rev, lb, pslot);
+    (void)pslot;
     const int ch = lb / tpp, pt = lb - ch * tpp;
     const int i = 1 + (pt % ntx) * 64 * V + lane * V, j = 1 + (pt / ntx) * S7_BY + wv;
     const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);
@@ -826,7 +829,7 @@ int op_correct(const G &g, T *u, const T *L, const T *x, const T *rowc = nullptr
             Prof p(WL_K_CORRECT, R.count());
             const XBc<T> xb = (xbc && xbc->on) ? *xbc : XBc<T>{0, 0, (T)0};
             hipLaunchKernelGGL((k_correct3<T>), dim3(tpp * nchunk), dim3(64 * S7_BY), 0, ctx().stream, g, u, L, x, rowc, ntx, tpp,
-                               tpp * nchunk, clen, R.lo[2], R.hi[2], xb);
+                               tpp * nchunk, clen, R.lo[2], R.hi[2], xb, sweep_rev());
             if (xdone) *xdone = xb.on != 0;
             return (int)hipGetLastError();
         }

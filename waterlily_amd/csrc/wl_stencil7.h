@@ -94,6 +94,7 @@ struct Gate {
     int f32 = 1;                    // the solver's element type is Float32 (scalars are rounded to it)
     int also_x = 0;                 // run also when only the deferred x update is owed (direction kernel)
     int inv = 0;                    // kind 0: the body runs when *active == 0 instead
+    int rev = 0;                    // every XCD walks its range of tiles backwards (set by the launchers, see sweep_rev)
 };
 struct Pre { int act; double s0, s1; };
 // pcg!'s scalar logic, shared by the in-kernel form (gate_open) and the k_finalize epilogues of op_pcg
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
     using Raw = typename SRC::Raw;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x;
-    const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);   // XCD-contiguous logical id
+    int lb, pslot;
+    tile_of(b, nblk, gate.rev, lb, pslot);                             // XCD-contiguous logical id
     const int ch = lb / tpp, pt = lb - ch * tpp;
     const int n0 = g.n[0], n1 = g.n[1], nxi = n0 - 2, nyi = n1 - 2;
     const int i = 1 + (pt % ntx) * 64 * V + lane * V;
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(64 * S7_BY) void k_stencil7(G g, SRC src, const T *
         block_red<(NRED > 0 ? NRED : 1), S7_BY>(acc, RED_SUM);
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int q = 0; q < NRED; ++q) partials[(long)q * gridDim.x + blockIdx.x] = acc[q];
+            for (int q = 0; q < NRED; ++q) partials[(long)q * gridDim.x + pslot] = acc[q];
         }
     }
 }
@@ -480,7 +482,8 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, LD ld, ST st, const T *rowc
     constexpr int V = Vec16<T>::V;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x;
-    const int lb = (nblk & 7) ? b : (b & 7) * (nblk >> 3) + (b >> 3);
+    int lb, pslot;
+    tile_of(b, nblk, gate.rev, lb, pslot);
     const int ch = lb / tpp, pt = lb - ch * tpp;
     const int i = 1 + (pt % ntx) * 64 * V + lane * V;
     const int j = __builtin_amdgcn_readfirstlane(1 + (pt / ntx) * 4 + wv);
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, LD ld, ST st, const T *rowc
         block_red<(NRED > 0 ? NRED : 1), 4>(acc, OP);
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int q = 0; q < NRED; ++q) partials[(long)q * gridDim.x + blockIdx.x] = acc[q];
+            for (int q = 0; q < NRED; ++q) partials[(long)q * gridDim.x + pslot] = acc[q];
         }
     }
 }
@@ -581,6 +584,7 @@ inline int launch_rowvec(int kclass, const G &g, LD ld, ST st, const T *rowc, do
     if (nblk > WL_MAXB) return -1;
     if (np) *np = nblk;
     Prof p(kclass, R.count());
+    gate.rev = sweep_rev();
     hipLaunchKernelGGL((k_rowvec<T, NRED, RK, LD, ST, OP>), dim3(nblk), dim3(256), 0, ctx().stream, g, ld, st, RK ? rowc : nullptr, partials,
                        ntx, tpp, nblk, clen, R.lo[2], R.hi[2], gate);
     return (int)hipGetLastError();
@@ -660,6 +664,7 @@ inline int launch_stencil7_r(int kclass, const G &g, SRC src, const T *L, const 
     if (nblk > WL_MAXB) return -1;   // plane too large for the partial buffer: caller falls back
     if (np) *np = nblk;
     Prof p(kclass, Rg.count());
+    gate.rev = sweep_rev();
     hipLaunchKernelGGL((k_stencil7<T, NRED, R, SRC, EPI>), dim3(nblk), dim3(64 * S7_BY), 0, ctx().stream, g, src, L, rowc, ea, eb, epi,
                        partials, ntx, tpp, nblk, clen, klo, khi, gate);
     return (int)hipGetLastError();
