@@ -354,7 +354,10 @@ int wl_prof_overlapped(int64_t *count);
  * component and neighbour side), out[3] all-gathers, out[4] bytes this rank sent in halo exchanges, out[5] bytes it
  * contributed to all-gathers */
 int wl_prof_comm(int64_t out[6]);
-int wl_prof_reset_comm(void);           /* zero these six counters only (wl_prof_reset zeroes them too) */
+int wl_prof_reset_comm(void);
+/* `reps` back-to-back all-reduces of one double, issued the way the solver issues them (mailbox or communicator): microseconds
+ * per all-reduce, timed on the device.  Every rank calls it with the same reps; 0 without a communicator. */
+int wl_prof_allreduce_us(int reps, double *us_per_op);           /* zero these six counters only (wl_prof_reset zeroes them too) */
 /* for the selected class: timed launches, their summed cells, summed milliseconds (synchronises) */
 int wl_prof_timed(int64_t *launches, int64_t *cells, double *ms);
 

@@ -74,6 +74,16 @@ def main():
         return vtk_roundtrip(rank, size, dims, L, kw)
     if case.startswith("mboxtimeout"):
         return mailbox_timeout(rank, size)
+    if case.startswith("arlat"):
+        us = C.c_double()
+        _lib.check(_lib.lib().wl_prof_allreduce_us(500, C.byref(us)))
+        out = {"us_per_allreduce": us.value, "mailbox": wd.mailbox_active(), "ranks": size}
+        dist.barrier()
+        wd.finalize()
+        if rank == 0:
+            print("RESULT " + json.dumps(out), flush=True)
+        dist.destroy_process_group()
+        return
     ref = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=None, **kw)
     slab = wd.Slab(rank, size, dims[2], ring=(2 in perdir))
     # "deep": keep every level a slab as long as the partition allows; default: replicate levels <= 2^21 cells

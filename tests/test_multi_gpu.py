@@ -175,6 +175,18 @@ def test_slabs_match_undecomposed(nproc, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,mailbox", [(2, "1"), (4, "1"), (2, "0")])
+def test_allreduce_latency_is_reported(nproc, mailbox):
+    """wl_prof_allreduce_us: device-timed cost of one scalar all-reduce as the solver issues them -- through the mailbox (2 and
+    4 ranks sharing the GPU) and through the transport's own all-reduce (here: host callbacks over gloo).  Printed with -s;
+    the mailbox figure is what DESIGN.md section 6 prices the 8-GPU step with (same PCIe round trips, more peers to poll)."""
+    out = run_workers("mg_worker.py", nproc, "arlat_f32", timeout=180, WL_MAILBOX=mailbox)
+    print(f"\nall-reduce of one double, {nproc} ranks on one GPU, {'mailbox' if out['mailbox'] else 'transport'}: {out['us_per_allreduce']:.1f} us")
+    assert out["mailbox"] == (mailbox == "1") and out["ranks"] == nproc
+    assert 0.5 < out["us_per_allreduce"] < (200.0 if out["mailbox"] else 20000.0)
+
+
+@pytest.mark.gpu
 def test_mailbox_allreduce_gives_up_on_a_missing_peer():
     """the waits of the mailbox all-reduce are bounded (wl_set_option(26)): a healthy round sums correctly; when a peer never
     posts, the waiting rank's kernel ends, and the library turns the flag into an error at its next synchronisation"""

@@ -157,6 +157,7 @@ def lib() -> C.CDLL:
         "wl_prof_counts": (i, [i, C.POINTER(i64), C.POINTER(i64)]),
         "wl_prof_comm": (i, [C.POINTER(i64)]),
         "wl_prof_reset_comm": (i, []),
+        "wl_prof_allreduce_us": (i, [i, dp]),
         "wl_prof_timed": (i, [C.POINTER(i64), C.POINTER(i64), dp]),
     }
     for name, (res, args) in sig.items():

@@ -1311,6 +1311,33 @@ int wl_prof_reset(void) {
     if (c.comm) for (int q = 0; q < 6; ++q) c.comm->cnt[q] = 0;
     return 0;
 }
+// back-to-back all-reduces of one double on the library's stream, as the solver issues them (local reduction of a few
+// partials + exchange), timed with two events: microseconds per all-reduce.  Every rank calls it with the same `reps`.
+int wl_prof_allreduce_us(int reps, double *us_per_op) {
+    Comm *cm = ctx().comm;
+    if (!us_per_op || reps < 1) return fail(WL_E_ARG, "wl_prof_allreduce_us: bad arguments", __FILE__, __LINE__);
+    *us_per_op = 0.0;
+    if (!cm || cm->size == 1) return 0;
+    int rc = 0;
+    Scratch &S = global_scratch(&rc);
+    WL_TRY(rc);
+    WL_HIP(hipMemsetAsync(S.partials, 0, sizeof(double) * 64, ctx().stream));
+    hipEvent_t a, b;
+    WL_HIP(hipEventCreate(&a));
+    WL_HIP(hipEventCreate(&b));
+    for (int w = 0; w < 3 && !rc; ++w) rc = reduce_allreduce<1>(S.partials, 64, RED_SUM, 0.0, S.st->red);   // warm-up
+    if (!rc) rc = (int)hipEventRecord(a, ctx().stream);
+    for (int q = 0; q < reps && !rc; ++q) rc = reduce_allreduce<1>(S.partials, 64, RED_SUM, 0.0, S.st->red);
+    if (!rc) rc = (int)hipEventRecord(b, ctx().stream);
+    if (!rc) rc = (int)hipEventSynchronize(b);
+    float ms = 0;
+    if (!rc) rc = (int)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (rc) return rc < 10000 ? fail(rc, "wl_prof_allreduce_us", __FILE__, __LINE__) : rc;
+    if (ctx().mbox && *ctx().mbox->err_host) return fail(WL_E_STATE, "mailbox all-reduce: gave up waiting for a peer rank", __FILE__, __LINE__);
+    *us_per_op = (double)ms * 1e3 / reps;
+    return 0;
+}
 int wl_prof_reset_comm(void) {
     if (ctx().comm) for (int q = 0; q < 6; ++q) ctx().comm->cnt[q] = 0;
     return 0;
