@@ -225,6 +225,18 @@ def test_slabs_match_without_overlap(nproc, case):
 
 
 @pytest.mark.gpu
+def test_two_slabs_at_the_size_of_a_bench_rank():
+    """The slab path at the size a rank of `bench.py --gpus N` works on -- 512x512x256 owned cells per rank (the 512^3 sphere on
+    two ranks sharing the GPU): the two-rows-per-thread 7-point kernels, the 64x8 conv_diff tiles and the 16 K-workgroup
+    streaming kernels in their decomposed form (split launches around the exchanges, partials of three launches laid end
+    to end), the mailbox and the hand-over to replicated levels -- must reproduce the undecomposed 512^3 run."""
+    out = run_workers("mg_worker.py", 2, "sphere_big_f32", timeout=900)
+    assert out["slab_nzl"][:2] == [256, 128] and out["slab_nzl"][-1] is None and out["mailbox"] and out["overlapped"] > 0
+    check(out, "f32")
+    check_collectives(out)
+
+
+@pytest.mark.gpu
 def test_vtk_write_restart_on_two_slabs(tmp_path):
     """maintests.jl:420-443 on a decomposed run: slab gather on write, slab scatter on restart (2 ranks sharing the GPU)."""
     out = run_workers("mg_worker.py", 2, "vtk_f32", WL_TMP=str(tmp_path))
