@@ -388,6 +388,19 @@ function init_slabs!(bcast, rank::Integer, nranks::Integer; device=rank)
     rank == 0 && chk(ccall((:wl_comm_unique_id, lib), Cint, (Ptr{UInt8},), id))
     bcast(id)
     chk(ccall((:wl_comm_init_rccl, lib), Cint, (Ptr{UInt8}, Cint, Cint), id, rank, nranks))
+    # scalars (dot products, CFL maximum, force sums) through the shared-memory mailbox instead of one ncclAllReduce each:
+    # rank 0 creates the POSIX shared-memory object, the others open it after the broadcast has ordered them behind it
+    name = zeros(UInt8, 64)
+    if rank == 0
+        nm = "/wlhip-$(getpid())-$(rand(UInt32))"
+        copyto!(name, 1, codeunits(nm), 1, ncodeunits(nm))
+        chk(ccall((:wl_comm_mailbox, lib), Cint, (Cstring, Cint), nm, 1))
+    end
+    bcast(name)                                        # (a broadcast completes on rank r only after rank 0 entered it: created first)
+    nm = unsafe_string(pointer(name))
+    rank == 0 || chk(ccall((:wl_comm_mailbox, lib), Cint, (Cstring, Cint), nm, 0))
+    bcast(name)                                        # everybody has mapped it: the name can go
+    rank == 0 && rm("/dev/shm" * nm; force=true)
 end
 finalize_slabs!() = chk(ccall((:wl_comm_finalize, lib), Cint, ()))
 """wl_grid of rank `r`'s z-slab of an undecomposed array of extents `Ng` (ghosts included): nz/P interior planes + 2 halo
