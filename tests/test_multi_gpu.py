@@ -153,7 +153,7 @@ def check(out, T):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,case", [(2, "sphere_deep_f32"), (4, "sphere_long_deep_f32"), (2, "donut_deep_f64"),
+@pytest.mark.parametrize("nproc,case", [(2, "sphere_deep_f32"), (2, "donut_deep_f64"),
                                         (2, "sphere_exit_deep_f32"), (2, "sphere_f32"),
                                         (2, "sphere_zper_deep_f32"), (4, "sphere_long_zper_deep_f64"),
                                         (2, "sphere_yzper_accel_deep_f64"), (2, "sphere_yper_exit_accel_f32"),
