@@ -798,7 +798,7 @@ int wl_comm_mailbox(const char *shm_name, int create) {
     if (!cm) return fail(WL_E_STATE, "wl_comm_mailbox: initialise the communicator first", __FILE__, __LINE__);
     if (!shm_name || shm_name[0] != '/') return fail(WL_E_ARG, "wl_comm_mailbox: name must start with '/'", __FILE__, __LINE__);
     if (cm->size > WL_MBOX_MAXRANKS) return fail(WL_E_ARG, "wl_comm_mailbox: too many ranks", __FILE__, __LINE__);
-    mailbox_release();
+    if (ctx().mbox) { (void)hipStreamSynchronize(ctx().stream); mailbox_release(); }   // (a replacement: nothing may still be polling the old one)
     const size_t bytes = ((2 * (size_t)cm->size * sizeof(MboxSlot) + 4095) / 4096) * 4096;
     const int fd = create ? shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600) : shm_open(shm_name, O_RDWR, 0600);
     if (fd < 0) return fail(WL_E_STATE, "wl_comm_mailbox: shm_open failed", __FILE__, __LINE__);
