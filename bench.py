@@ -96,6 +96,36 @@ def donut(dims, T, Re=1000.0, device="cuda:0", padded=True):
     return S.Simulation(tuple(dims), (1.0, 0.0, 0.0), R, nu=R / Re, body=AutoBody(sdf), T=T, device=device, padded=padded)
 
 
+def moving_cylinder(dims, T, Re=1000.0, device="cuda:0", padded=True):
+    """A circular cylinder (axis along z) translating with unit speed along x through fluid at rest, re-measured EVERY step
+    (`sim_step!`'s default, remeasure=true): `norm2(x[1:2] .- center) - radius` under `map(x,t) = x .- (U t, 0, 0)`, the 3-D
+    moving-cylinder case of the reference's benchmark suite (README.md:145-151, WaterLily-Benchmarks).  A parametric body:
+    measure! and the changed-rows update!(pois) run as HIP kernels (csrc/wl_measure.h)."""
+    from waterlily_amd import body as B
+    from waterlily_amd import sim as S
+    m = min(dims)
+    radius = m / 16
+    body = B.Cylinder((m / 4, dims[1] / 2, 0.0), radius, 3, map=B.translation(3, v=(1.0, 0.0, 0.0)))
+    return S.Simulation(tuple(dims), (0.0, 0.0, 0.0), 2 * radius, U=1.0, nu=2 * radius / Re, body=body, T=T, device=device, padded=padded)
+
+
+def tgv(dims, T, Re=1600.0, device="cuda:0", padded=True):
+    """3-D Taylor-Green vortex in the box (no body): the reference's README / benchmark TGV case, u = (-sin x cos y cos z,
+    cos x sin y cos z, 0) with kappa = pi / L, L = m / 2"""
+    from waterlily_amd import sim as S
+    m = min(dims)
+    Lc = m / 2
+    k = np.pi / Lc
+
+    def ulam(i, x):
+        if i == 0:
+            return -np.sin(k * x[0]) * np.cos(k * x[1]) * np.cos(k * x[2])
+        if i == 1:
+            return np.cos(k * x[0]) * np.sin(k * x[1]) * np.cos(k * x[2])
+        return 0.0 * x[0]
+    return S.Simulation(tuple(dims), (0.0, 0.0, 0.0), Lc, U=1.0, nu=Lc / Re, ulam=ulam, T=T, device=device, padded=padded)
+
+
 def _cpu_case(dims, T, Re, steps):
     """one CPU point: the oracle (oracle/wl_oracle.c, OpenMP; body measured by oracle/geometry.py) on the README's
     circle / sphere case, `steps` steps after one warm-up step, remeasure=false"""
@@ -149,7 +179,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=8, help="timed steps of the C2 CPU baseline (256^3: about 0.5 s per step on 16 cores)")
     ap.add_argument("--cpu-c1-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--body", default="sphere", choices=["sphere", "donut"], help="donut: BASELINE configs[4] (use with --dtype f64)")
+    ap.add_argument("--body", default="sphere", choices=["sphere", "donut", "cylinder", "tgv"],
+                    help="donut: BASELINE configs[4] (use with --dtype f64); cylinder: moving body, measure! every step (use with --dtype f64: the reference's Float32 solver stalls on it from 256^3, DESIGN.md section 5); tgv: no body")
     ap.add_argument("--layout", default="padded", choices=["padded", "dense"],
                     help="padded: rows 128-B aligned (default); dense: the reference's column-major layout (pitch N+2)")
     ap.add_argument("--kernel", default=None, help="force the kernel class reported in `roofline`")
@@ -202,7 +233,9 @@ def main():
     # global grid is 512 x 512 x 512N; --grid gives an explicit global grid instead (strong scaling).
     dims = tuple(args.grid) if args.grid else (m, m, m * world)
     scaling = "strong" if args.grid else "weak"
-    sim = (sphere if args.body == "sphere" else donut)(dims, T, device=dev, padded=(args.layout == "padded"))
+    make = {"sphere": sphere, "donut": donut, "cylinder": moving_cylinder, "tgv": tgv}[args.body]
+    sim = make(dims, T, device=dev, padded=(args.layout == "padded"))
+    remeasure = args.body == "cylinder"        # the moving body is re-measured every step (sim_step!'s default)
     ncell_global = int(np.prod(dims))
     ncell = ncell_global // world            # cells per rank: threshold for "finest level" launches
     names = class_table(L)
@@ -218,14 +251,14 @@ def main():
         """one extra step with every finest-level launch of class nm bracketed by hipEvents"""
         _lib.check(L.wl_prof_reset())
         _lib.check(L.wl_prof_select(names[nm], int(0.9 * ncell)))
-        S.sim_step(sim, remeasure=False)
+        S.sim_step(sim, remeasure=remeasure)
         nl, nc, ms = C.c_int64(), C.c_int64(), C.c_double()
         _lib.check(L.wl_prof_timed(C.byref(nl), C.byref(nc), C.byref(ms)))
         _lib.check(L.wl_prof_select(-1, 0))
         return {"launches": nl.value, "ms": ms.value, "cells": nc.value}
 
     for w in range(args.warmup):
-        S.sim_step(sim, remeasure=False)
+        S.sim_step(sim, remeasure=remeasure)
     sync()
     # each finest-level class is timed in one extra warm-up step: finds the dominant kernel, feeds the smoother objects
     classes = ["pcg_mult_dot", "pcg_update", "pcg_direction", "smooth", "prolongate", "conv_diff", "bdim", "residual", "correct",
@@ -242,7 +275,7 @@ def main():
     for it in range(args.steps):
         if it == args.steps - 1 and world > 1:
             _lib.check(L.wl_prof_reset_comm())   # count the collectives of the last timed step only (host counters: no GPU work)
-        S.sim_step(sim, remeasure=False)
+        S.sim_step(sim, remeasure=remeasure)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:  # MAX over ranks
@@ -303,8 +336,9 @@ def main():
         "metric": "MLUPS (cell-updates/s) per sim_step!, 3D sphere", "value": mlups, "unit": "MLUPS",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"3D {args.body} {dims[0]}x{dims[1]}x{dims[2]}, Re={3700 if args.body == 'sphere' else 1000}, {args.dtype}, uniform inflow, "
-                               f"remeasure=false" + (", dense layout" if args.layout == "dense" else "") + (" (BASELINE configs[2])" if world == 1 and not args.grid and m == 512
+        "config": {"workload": f"3D {args.body} {dims[0]}x{dims[1]}x{dims[2]}, Re={ {'sphere': 3700, 'tgv': 1600}.get(args.body, 1000)}, {args.dtype}, "
+                               + ("uniform inflow, remeasure=false" if args.body in ("sphere", "donut") else
+                                  ("body moving through fluid at rest, remeasure=true (native measure! + changed-rows update! every step)" if remeasure else "no body")) + (", dense layout" if args.layout == "dense" else "") + (" (BASELINE configs[2])" if world == 1 and not args.grid and m == 512
                                                      and args.dtype == "f32" and args.body == "sphere" else "" if world == 1 else
                                                      f", z-slabs over {world} GPUs"),
                    "transport": transport, "comm_ranks": cn.value,
