@@ -80,18 +80,22 @@ Base.setindex!(a::HIPArray, v, I::CartesianIndex) = (a[Tuple(I)...] = v)
 # ---- Base / LinearAlgebra generics the path calls on arrays (SURVEY.md 8b): device reductions where the library has one.
 # wl_dot / wl_sum / wl_max reduce over inside(a); every array the path reduces (Poisson.jl:94,126-146; Flow.jl:174) has
 # zero ghost entries there, see DESIGN.md section 7.1.  Vector fields (trailing component axis) take the host route.
-function reduce_lib(sym, a::HIPArray{T}, b=nothing) where T
-    o = Ref{Cdouble}()
-    if b === nothing
-        chk(ccall((sym, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ref{Cdouble}), dtype(T), grid(a), a.ptr, o))
-    else
-        chk(ccall((sym, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cdouble}), dtype(T), grid(a), a.ptr, b.ptr, o))
+# (the function name of a `ccall` has to be a constant: one method per entry point, generated here)
+for (fn, sym) in ((:lib_sum, :wl_sum), (:lib_max, :wl_max))
+    @eval function $fn(a::HIPArray{T}) where T
+        o = Ref{Cdouble}()
+        chk(ccall(($(QuoteNode(sym)), lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ref{Cdouble}), dtype(T), grid(a), a.ptr, o))
+        T(o[])
     end
+end
+function lib_dot(a::HIPArray{T}, b::HIPArray{T}) where T
+    o = Ref{Cdouble}()
+    chk(ccall((:wl_dot, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cdouble}), dtype(T), grid(a), a.ptr, b.ptr, o))
     T(o[])
 end
-Base.sum(a::HIPArray{T,N}) where {T,N} = N <= 3 ? reduce_lib(:wl_sum, a) : sum(Array(a))
-Base.maximum(a::HIPArray{T,N}) where {T,N} = N <= 3 ? reduce_lib(:wl_max, a) : maximum(Array(a))
-LinearAlgebra.dot(a::HIPArray{T,N}, b::HIPArray{T,N}) where {T,N} = N <= 3 ? reduce_lib(:wl_dot, a, b) : LinearAlgebra.dot(Array(a), Array(b))
+Base.sum(a::HIPArray{T,N}) where {T,N} = N <= 3 ? lib_sum(a) : sum(Array(a))
+Base.maximum(a::HIPArray{T,N}) where {T,N} = N <= 3 ? lib_max(a) : maximum(Array(a))
+LinearAlgebra.dot(a::HIPArray{T,N}, b::HIPArray{T,N}) where {T,N} = N <= 3 ? lib_dot(a, b) : LinearAlgebra.dot(Array(a), Array(b))
 
 # ---- broadcast (`.=`, `.*=`, `./=`, Flow.jl:37,139,144,154 -- inside mom_step! these never run: the override below
 # replaces the whole step): host fallback, D2H -> Base broadcast -> H2D
@@ -302,6 +306,7 @@ function ParametricBody(family::Symbol, params; map=nothing)
     P = Float64.(collect(params))
     sdf = family == :sphere ? (ξ, t) -> √sum(abs2, ξ .- P[1:length(ξ)]) - P[4] :
           family == :torus  ? (ξ, t) -> √((ξ[1] - P[1])^2 + (√((ξ[2] - P[2])^2 + (ξ[3] - P[3])^2) - P[4])^2) - P[5] :
+          family == :cylinder ? (ξ, t) -> √sum(ntuple(q -> P[4+q] * (ξ[q] - P[q])^2, length(ξ))) - P[4] :   # m = 1 on the axes of the circle
                               (ξ, t) -> √sum(abs2, ξ .- SVector(clamp(ξ[1], -P[1], P[1]), ntuple(_ -> 0, length(ξ) - 1)...)) - P[2]
     amap = map === nothing ? ((x, t) -> x) : ((x, t) -> ((A, b) = map(t); A * x + b))
     ParametricBody(family, P, map, WaterLily.AutoBody(sdf, amap))
@@ -336,9 +341,10 @@ function measure!(a::Flow{N,T,<:HIPArray}, body::ParametricBody; t=zero(T), ϵ=1
     nothing
 end
 # measure!(sim, t)  src/WaterLily.jl:116-119: the native measure! is followed by the changed-rows update!(pois)
-function measure!(sim::Simulation{D,T,<:HIPArray}, t=sum(sim.flow.Δt)) where {D,T}
+# (`Simulation` carries no type parameters, WaterLily.jl:59-65: the method is the reference's own for every other simulation)
+function measure!(sim::Simulation, t=sum(sim.flow.Δt))
     measure!(sim.flow, sim.body; t, ϵ=sim.ϵ)
-    sim.body isa ParametricBody ? update!(sim.pois, sim.flow) : update!(sim.pois)
+    (sim.flow.p isa HIPArray && sim.body isa ParametricBody) ? update!(sim.pois, sim.flow) : update!(sim.pois)
 end
 # nds band of a parametric body (Metrics.jl:84-87): wl_body_nds on the band cells measure! listed; returns element offsets + vectors
 function band(p::HIPArray, body::ParametricBody, t)
