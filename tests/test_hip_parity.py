@@ -543,6 +543,54 @@ def test_c5_256_f64_torus_against_the_oracle():
     assert np.allclose(O.pressure_force(so), S.pressure_force(sh), rtol=1e-8, atol=1e-9)
 
 
+def _oracle_moving_cylinder(m, T):
+    """the oracle twin of bench.moving_cylinder (closed-form geometry, oracle/geometry.py)"""
+    R = m / 16
+    body = G.Body(G.Cylinder((m / 4, m / 2, 0.0), R, axes=(0, 1)), G.Translate(v=(1.0, 0.0, 0.0)))
+    return O.Simulation((m, m, m), (0.0, 0.0, 0.0), 2 * R, U=1.0, nu=2 * R / 1000, body=body, T=T)
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_bench_moving_cylinder_case_against_the_oracle(T):
+    """`bench.py --body cylinder`: a cylinder through the z walls translating through fluid at rest, measure! + update!
+    every step (sim_step!'s default) -- native kernels against the oracle at 64^3: V-cycle counts, time steps, u, p."""
+    import bench
+    m = 64
+    so, sh = _oracle_moving_cylinder(m, T), bench.moving_cylinder((m, m, m), T)
+    for _ in range(4):
+        O.sim_step(so)
+        S.sim_step(sh)
+    assert so.pois.n == sh.pois.n, (so.pois.n, sh.pois.n)
+    assert np.allclose(so.flow.dt, sh.flow.dt, rtol=rtol(T) * 10, atol=0)
+    same(sh.flow.u, so.flow.u, exact=False, tol=rtol(T) * 50)
+    same(sh.flow.p, so.flow.p, exact=False, tol=rtol(T) * 500)
+
+
+def test_float32_solver_stall_on_the_moving_cylinder_is_the_reference_algorithm():
+    """from 256^3 the reference's Float32 solver cannot bring r.r below tol = 1e-4 on this case -- cells
+    frozen by set_diag! (D^2 < 2 eps(T), Poisson.jl:44) keep the residual L*d(eps) their neighbours leave on them.  The HIP path
+    must stall exactly where the reference's algorithm does: the V-cycle counts of the first two steps at 256^3 Float32 are
+    those the CPU oracle takes ([3, 2] then [32, 32], recorded in profiles/r03c_cylinder_vcycles.txt; the oracle needs a
+    minute for them, so they are pinned here as numbers), with the solver log showing the floor; Float64 converges."""
+    import bench
+    m = 256
+    sh = bench.moving_cylinder((m, m, m), np.float32)
+    S.sim_step(sh)
+    S.solver_log(sh.pois, True)
+    S.sim_step(sh)
+    rows = S.read_solver_log(sh.pois)
+    S.solver_log(sh.pois, False)
+    assert sh.pois.n == [3, 2, 32, 32], sh.pois.n
+    first = rows[:33]                                   # n = 0 .. 32 of the predictor's solve
+    assert first[0, 0] == 0 and first[4, 0] == 4
+    assert 1e-4 < first[4:15, 2].min() and first[4:15, 2].max() < 2e-3     # parked on the floor, above tol
+    del sh
+    sd = bench.moving_cylinder((m, m, m), np.float64)
+    for _ in range(2):
+        S.sim_step(sd)
+    assert sd.pois.n == [3, 2, 4, 2], sd.pois.n
+
+
 @pytest.mark.parametrize("T", TYPES)
 @pytest.mark.parametrize("dims", [(48, 32), (32, 32, 32)])
 def test_mom_step_dense_julia_layout(T, dims):
