@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""HIP path and CPU oracle side by side over MANY steps of a BASELINE configuration (README circle / sphere case,
+remeasure=false): per step the V-cycle counts of both solves, the relative difference of the time step, max |du| / U,
+max |dp| / max |p| and the pressure force of both.  The tests compare a handful of steps; this is the long horizon.
+(tools/ may use the oracle as a checker, like tests/: nothing here is product code.)
+
+usage: longparity.py <c1|c2|NxNxN> <f32|f64> <steps> [every]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import geometry as G  # noqa: E402
+from oracle import wl_oracle as O  # noqa: E402
+from waterlily_amd import body as B  # noqa: E402
+from waterlily_amd import sim as S  # noqa: E402
+
+case, tname, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+every = int(sys.argv[4]) if len(sys.argv) > 4 else max(1, steps // 25)
+T = {"f32": np.float32, "f64": np.float64}[tname]
+dims, Re = {"c1": ((192, 64), 100.0), "c2": ((256, 256, 256), 3700.0)}.get(case) or (tuple(int(v) for v in case.split("x")), 3700.0)
+D = len(dims)
+m = dims[-1]
+radius, center = m / 8, m / 2 - 1
+U = (1.0,) + (0.0,) * (D - 1)
+so = O.Simulation(dims, U, 2 * radius, nu=2 * radius / Re, body=G.Body(G.Sphere(center, radius)), T=T)
+sh = S.Simulation(dims, U, 2 * radius, nu=2 * radius / Re, body=B.Sphere((center,) * D, radius, D), T=T)
+print(f"# {dims} {tname} Re={Re:g}: oracle (CPU) vs HIP, remeasure=false")
+print("# step  V-cycles(oracle)  V-cycles(HIP)  d(dt)/dt   max|du|/U   max|dp|/max|p|   force_x(oracle)  force_x(HIP)   rel")
+worst = {"u": 0.0, "p": 0.0, "dt": 0.0, "f": 0.0, "nmis": 0}
+for k in range(1, steps + 1):
+    O.sim_step(so, remeasure=False)
+    S.sim_step(sh, remeasure=False)
+    no, nh = so.pois.n[-2:], sh.pois.n[-2:]
+    ddt = abs(so.flow.dt[-1] - sh.flow.dt[-1]) / so.flow.dt[-1]
+    worst["dt"] = max(worst["dt"], ddt)
+    worst["nmis"] += int(list(no) != list(nh))
+    if k % every == 0 or k == steps or list(no) != list(nh):
+        du = np.abs(S.to_host(sh.flow.u).astype(np.float64) - so.flow.u).max()
+        pm = max(np.abs(so.flow.p).max(), 1e-300)
+        dp = np.abs(S.to_host(sh.flow.p).astype(np.float64) - so.flow.p).max() / pm
+        fo, fh = O.pressure_force(so), S.pressure_force(sh)
+        rel = np.abs(fo - fh).max() / max(np.abs(fo).max(), 1e-300)
+        worst["u"], worst["p"], worst["f"] = max(worst["u"], du), max(worst["p"], dp), max(worst["f"], rel)
+        print(f"{k:6d}  {str(list(no)):>16s}  {str(list(nh)):>13s}  {ddt:9.2e}  {du:10.3e}  {dp:14.3e}  {fo[0]:15.8e}  {fh[0]:14.8e}  {rel:8.1e}", flush=True)
+print(f"# worst over the run: max|du|/U {worst['u']:.3e}, max|dp|/max|p| {worst['p']:.3e}, d(dt)/dt {worst['dt']:.2e}, force {worst['f']:.1e}, "
+      f"steps with different V-cycle counts: {worst['nmis']} of {steps}")
