@@ -532,6 +532,17 @@ def test_c3_full_size_512_f32_against_the_oracle():
     check_step(so, sh, np.float32, 2)
 
 
+def test_c2_full_size_256_f32_twelve_steps_against_the_oracle():
+    """BASELINE config C2 itself (256^3 Float32 sphere, Re=3700; the CPU-baseline case of bench.py) over twelve steps:
+    identical V-cycle counts in every solve, time steps, u, p and the pressure force.  (tools/longparity.py runs the same pair
+    for 60 steps: bitwise equal fields throughout, profiles/r03c_longparity_c2_256_f32_60steps.txt.)"""
+    m = 256
+    R, c = m / 8, m / 2 - 1
+    so, sh = pair((m, m, m), (1.0, 0.0, 0.0), 2 * R, nu=2 * R / 3700, body=bodies.sphere(c, R), T=np.float32, geometry="device")
+    check_step(so, sh, np.float32, 12)
+    assert np.allclose(O.pressure_force(so), S.pressure_force(sh), rtol=1e-4, atol=1e-4)
+
+
 def test_c5_256_f64_torus_against_the_oracle():
     """BASELINE config C5's case -- torus AutoBody, Float64, Re=1000 -- at 256^3 (the largest 3-D Float64 size the CPU oracle
     steps in seconds): 2 steps, identical V-cycle counts and time steps, u within 1e-10 and p within 1e-9 of their maxima,
