@@ -57,6 +57,9 @@ def main():
     elif "move" in case:   # parametric sphere drifting along z across the slab boundaries: native measure! kernels + the
         from waterlily_amd import body as B                      # changed-rows update!(pois) every step
         body, L, nu = B.Sphere(c, R, 3, map=B.translation(3, v=(0.2, 0.0, 0.9))), 2 * R, 2 * R / 500
+    elif "big" in case:    # (parametric sphere: the closure + autograd measure of 134 M cells on the host takes a minute per rank)
+        from waterlily_amd import body as B
+        body, L, nu = B.Sphere(c, R, 3), 2 * R, 2 * R / 3700
     else:
         body, L, nu = AutoBody(lambda x, t: norm2(x - c) - R), 2 * R, 2 * R / 3700
     perdir = ()
@@ -89,8 +92,24 @@ def main():
     # "deep": keep every level a slab as long as the partition allows; default: replicate levels <= 2^21 cells
     sim = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=slab, replicate_cells=0 if "deep" in case else 1 << 21, **kw)
     out = {"rank": rank, "levels": [(tuple(l.layout.Ng), l.layout.slab is not None) for l in sim.pois.levels]}
+    big = "big" in case
+
+    def on_device(a, b, rel):
+        """max |slab - undecomposed| over the planes this rank owns, on the GPU, then the max over the ranks (the big case:
+        gathering 512^3 fields through pickled host arrays takes a minute)"""
+        sl = a._wl_slab
+        own = a[:, :, sl.own_lo:sl.own_hi + 1]
+        d = (own - b[:, :, sl.kz0 + sl.own_lo:sl.kz0 + sl.own_hi + 1]).abs().max().double().cpu()
+        mx = b.abs().max().double().cpu() if rel else torch.ones((), dtype=torch.float64)
+        v = torch.stack([d, mx])
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v[0] / max(1e-30, float(v[1])))
+
     # static fields after construction
     for k in ("u", "mu0", "mu1", "V"):
+        if big:
+            out["init_" + k] = on_device(getattr(sim.flow, k), getattr(ref.flow, k), False)
+            continue
         out["init_" + k] = float(np.max(np.abs(S.gather(getattr(sim.flow, k)) - S.to_host(getattr(ref.flow, k)))))
     nsteps = 1 if "big" in case else 3
     for _ in range(nsteps):
@@ -99,6 +118,9 @@ def main():
     out["n_ref"], out["n_slab"] = list(ref.pois.n), list(sim.pois.n)
     out["dt_ref"], out["dt_slab"] = list(ref.flow.dt), list(sim.flow.dt)
     for k in ("u", "p", "f"):
+        if big:
+            out["d_" + k] = on_device(getattr(sim.flow, k), getattr(ref.flow, k), True)
+            continue
         a, b = S.gather(getattr(sim.flow, k)), S.to_host(getattr(ref.flow, k))
         if 2 in perdir and k == "f":
             # f on the two z GHOST planes: the reference leaves partial flux sums there (conv_diff! never periodic-copies
