@@ -1,0 +1,179 @@
+"""Structural pins of the oracle's 3-D operators.
+
+The reference's analytic tests of conv_diff! and of the solver are 2-D (test/maintests.jl:172-180 impulsive box flow,
+:232-253 Taylor-Green vortex against its decay, :280-302 accelerating channel).  Two properties carry them over to the 3-D
+code the BASELINE configurations run, without any further restatement of the formulas:
+
+  * EXTRUSION: a 3-D field that does not depend on z and has w = 0 is a stack of 2-D fields.  Every z-flux and every
+    z-difference of conv_diff! (src/Flow.jl:36-60) is then an exact 0, so the x and y components of the 3-D result must equal
+    the 2-D result BIT FOR BIT in every plane, and the z component must be exactly 0; the 7-point mult (src/Poisson.jl:69-75)
+    of an extruded x with L_z = 1 differs from the 5-point one only by  x*(-2) + x + x.
+  * PERMUTATION: conv_diff!, mult, residual!, restrict!/prolongate! treat the three axes alike (the loops `for i, j` of
+    Flow.jl:41-50).  Rotating the axes of the input (and the components of a vector field with them) must rotate the output;
+    only the order in which the flux contributions are added to a cell changes (a few ulp).
+
+No GPU, no product code: oracle/ only."""
+import numpy as np
+import pytest
+
+from oracle import wl_oracle as O
+
+TYPES = [np.float32, np.float64]
+
+
+def smooth_vec(shape, T, seed, D):
+    """a smooth vector field with O(1) values and gradients, non-zero on the boundary faces too"""
+    rng = np.random.default_rng(seed)
+    u = O.zeros(tuple(shape) + (D,), T)
+    ph = rng.uniform(0, 2 * np.pi, size=(D, D))
+    kk = rng.uniform(0.15, 0.45, size=(D, D))
+    amp = rng.uniform(0.5, 1.5, size=D)
+    for i in range(D):
+        x = O.loc(i, shape)
+        v = amp[i] * np.ones(shape)
+        for d in range(D):
+            v = v * np.sin(kk[i, d] * x[d] + ph[i, d])
+        u[..., i] = (v + 0.3 * (i + 1)).astype(T)
+    return u
+
+
+def conv_diff(u, nu, perdir=()):
+    r = O.zeros(u.shape, u.dtype)
+    Phi = O.zeros(u.shape[:-1], u.dtype)
+    O.conv_diff(r, u, Phi, nu=nu, perdir=perdir)
+    return r
+
+
+@pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("zper", [False, True], ids=["z-walls", "z-periodic"])
+def test_conv_diff_of_an_extruded_field_is_the_2d_result_in_every_plane(T, zper):
+    n = (14, 11)
+    nz = 8
+    u2 = smooth_vec(n, T, 1, 2)
+    O.BC(u2, (0.4, -0.2))
+    r2 = conv_diff(u2, 0.07)
+    u3 = O.zeros(n + (nz, 3), T)
+    u3[..., 0] = u2[:, :, None, 0]
+    u3[..., 1] = u2[:, :, None, 1]
+    perdir = (2,) if zper else ()
+    O.BC(u3, (0.4, -0.2, 0.0), False, perdir)
+    assert np.all(u3[..., 2] == 0) and np.all(u3[:, :, 3, 0] == u2[..., 0])      # BC! keeps the stack a stack
+    r3 = conv_diff(u3, 0.07, perdir)
+    ins = (slice(1, -1), slice(1, -1))
+    for k in range(1, nz - 1):
+        for c in (0, 1):
+            assert np.array_equal(r3[ins + (k, c)], r2[ins + (c,)]), (k, c)
+    assert np.all(r3[1:-1, 1:-1, 1:-1, 2] == 0)
+
+
+def rot_vec(u):
+    """axes (x, y, z) -> (y, z, x): u'(y, z, x)[c'] with component c' = (c - 1) mod 3, i.e. u'_0 = u_1, u'_1 = u_2, u'_2 = u_0"""
+    v = np.transpose(u, (1, 2, 0, 3))[..., [1, 2, 0]]
+    return np.asfortranarray(v)
+
+
+def rot_sc(a):
+    return np.asfortranarray(np.transpose(a, (1, 2, 0)))
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_conv_diff_commutes_with_a_rotation_of_the_axes(T):
+    n = (10, 12, 9)
+    U = (0.3, -0.5, 0.2)
+    u = smooth_vec(n, T, 2, 3)
+    O.BC(u, U)
+    r = conv_diff(u, 0.05)
+    ur = rot_vec(u)
+    assert ur.shape == (12, 9, 10, 3)
+    chk = ur.copy(order="F")
+    O.BC(chk, (U[1], U[2], U[0]))
+    assert np.array_equal(chk, ur)                                  # the rotated field satisfies the rotated BC!
+    rr = conv_diff(ur, 0.05)
+    want = rot_vec(r)
+    ins = (slice(1, -1),) * 3
+    tol = 8 * np.finfo(T).eps * np.abs(want[ins]).max()
+    assert np.abs(rr[ins] - want[ins]).max() <= tol
+    assert np.abs(want[ins]).max() > 0.05                           # (the comparison is of something)
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_poisson_operators_commute_with_a_rotation_of_the_axes(T):
+    """mult, residual!, Jacobi!+increment!, restrict!, prolongate! and restrictL! on an anisotropic coefficient field"""
+    n = (10, 14, 18)
+    rng = np.random.default_rng(5)
+
+    def build(L, x, z):
+        p = O.MultiLevelPoisson(x, L, z, maxlevels=2)
+        return p
+
+    L = O.zeros(n + (3,), T)
+    L[...] = rng.uniform(0.2, 1.0, size=L.shape).astype(T)
+    O.BC(L, (0.0, 0.0, 0.0))
+    x = O.zeros(n, T)
+    x[1:-1, 1:-1, 1:-1] = rng.uniform(-1, 1, size=tuple(m - 2 for m in n)).astype(T)
+    z = O.zeros(n, T)
+    z[1:-1, 1:-1, 1:-1] = rng.uniform(-1, 1, size=tuple(m - 2 for m in n)).astype(T)
+    z[1:-1, 1:-1, 1:-1] -= z[1:-1, 1:-1, 1:-1].mean(dtype=np.float64).astype(T)
+    Lr, xr, zr = rot_vec(L), rot_sc(x), rot_sc(z)
+    a, b = build(L, x, z), build(Lr, xr, zr)
+    eps = np.finfo(T).eps
+    ins = (slice(1, -1),) * 3
+
+    def same(u, v, what, k=16):
+        w = rot_sc(u)
+        assert np.abs(v[ins] - w[ins]).max() <= k * eps * max(1.0, np.abs(w[ins]).max()), what
+
+    assert np.array_equal(b.levels[0].D[ins], rot_sc(a.levels[0].D)[ins]) or np.abs(b.levels[0].D[ins] - rot_sc(a.levels[0].D)[ins]).max() <= 8 * eps * 6
+    # coarse coefficients (restrictL!) and their diagonal
+    la, lb = a.levels[1], b.levels[1]
+    assert np.abs(lb.L[1:-1, 1:-1, 1:-1] - rot_vec(la.L)[1:-1, 1:-1, 1:-1]).max() <= 8 * eps * 4
+    same(O.mult(a, x).copy(order="F"), O.mult(b, xr).copy(order="F"), "mult")
+    # mult overwrote z (= p.z): restore the right-hand side
+    z0 = rng.uniform(-1, 1, size=tuple(m - 2 for m in n)).astype(T)
+    z0 -= z0.mean(dtype=np.float64).astype(T)
+    z[...] = 0
+    z[1:-1, 1:-1, 1:-1] = z0
+    zr[...] = rot_sc(z)
+    O.residual(a)
+    O.residual(b)
+    same(a.levels[0].r, b.levels[0].r, "residual!")
+    O.Jacobi(a)
+    O.Jacobi(b)
+    same(a.levels[0].r, b.levels[0].r, "Jacobi!+increment! (r)")
+    same(x, xr, "Jacobi!+increment! (x)")
+    O.restrict(la.r, a.levels[0].r)
+    O.restrict(lb.r, b.levels[0].r)
+    same(la.r, lb.r, "restrict!", k=64)
+    la.x[...] = 0
+    la.x[1:-1, 1:-1, 1:-1] = rng.uniform(-1, 1, size=tuple(m - 2 for m in la.x.shape)).astype(T)
+    lb.x[...] = rot_sc(la.x)
+    O.prolongate(a.levels[0].eps, la.x)
+    O.prolongate(b.levels[0].eps, lb.x)
+    assert np.array_equal(b.levels[0].eps[ins], rot_sc(a.levels[0].eps)[ins])
+
+
+@pytest.mark.parametrize("T", TYPES)
+def test_mult_of_an_extruded_field_is_the_5_point_result(T):
+    n = (12, 10)
+    nz = 8
+    rng = np.random.default_rng(3)
+    L2 = O.zeros(n + (2,), T)
+    L2[...] = rng.uniform(0.3, 1.0, size=L2.shape).astype(T)
+    O.BC(L2, (0.0, 0.0))
+    x2 = O.zeros(n, T)
+    x2[1:-1, 1:-1] = rng.uniform(-1, 1, size=(n[0] - 2, n[1] - 2)).astype(T)
+    z2 = O.zeros(n, T)
+    p2 = O.Poisson(x2, L2, z2)
+    y2 = O.mult(p2, x2).copy(order="F")
+    # 3-D, z-periodic stack with L_z = 0: the z faces drop out of the diagonal and of the sum -- the very same operations
+    L3 = O.zeros(n + (nz, 3), T)
+    L3[..., 0] = L2[:, :, None, 0]
+    L3[..., 1] = L2[:, :, None, 1]
+    x3 = O.zeros(n + (nz,), T)
+    x3[...] = x2[:, :, None]
+    z3 = O.zeros(n + (nz,), T)
+    p3 = O.Poisson(x3, L3, z3, perdir=(2,))
+    y3 = O.mult(p3, x3)
+    for k in range(1, nz - 1):
+        assert np.array_equal(y3[1:-1, 1:-1, k], y2[1:-1, 1:-1]), k
+    assert np.array_equal(p3.D[1:-1, 1:-1, 3], p2.D[1:-1, 1:-1]) and np.array_equal(p3.iD[1:-1, 1:-1, 3], p2.iD[1:-1, 1:-1])
