@@ -815,6 +815,22 @@ def test_ref_circle_in_accelerating_flow():  # maintests.jl:304-316
     assert all(n <= 2 for n in s.pois.n)
 
 
+@pytest.mark.parametrize("radius,N", [(16, 128), (32, 384)])
+def test_sphere_in_accelerating_flow_added_mass_on_the_hip_path(radius, N):
+    """maintests.jl:304-316 in 3-D (tests/test_oracle_3d_structure.py holds the oracle to the same numbers): the added mass of
+    a sphere is half its displaced mass, pressure_force / (2/3 pi R^3) = [-1, 0, 0] +- 0.04, peak speed ~1.5 U; native measure!.
+    The second case is out of the CPU oracle's reach in a test (56 M cells; 12 R box, 32-cell radius): closer to both limits."""
+    from waterlily_amd import body as B
+    s = S.Simulation((N, N, N), lambda i, t: t if i == 0 else 0.0 * t, radius, U=1, body=B.Sphere(N / 2, radius, 3), T=np.float32)
+    S.sim_step(s)
+    f = S.pressure_force(s) / (2 / 3 * math.pi * radius ** 3)
+    assert np.allclose(f, [-1, 0, 0], atol=0.04 if radius == 16 else 0.02), f
+    u = S.to_host(s.flow.u)
+    assert u.max() / u[1, 1, 1, 0] > (1.4 if radius == 16 else 1.44), u.max() / u[1, 1, 1, 0]
+    assert all(n <= 2 for n in s.pois.n)
+    print(f"\nadded mass of the sphere R={radius} in {N}^3: force/(2/3 pi R^3) = {f}, peak speed {u.max() / u[1, 1, 1, 0]:.4f}")
+
+
 def test_ref_periodic_TGV():  # maintests.jl:232-253
     L = 64
     k = 2 * math.pi / L
