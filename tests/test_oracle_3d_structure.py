@@ -254,3 +254,13 @@ def test_sphere_in_accelerating_flow_has_half_its_displaced_mass_added():
     assert np.allclose(f, [-1, 0, 0], atol=0.04), f
     assert s.flow.u.max() / s.flow.u[1, 1, 1, 0] > 1.4
     assert all(n <= 2 for n in s.pois.n)
+
+
+def test_impulsive_flow_in_a_3d_box():
+    """test/maintests.jl:172-180 (16^2 Float32: after one mom_step! the uniform flow stays uniform, L2 < 2e-5 / 1e-5) in a 16^3
+    box with a third velocity component; same bounds (measured 3e-6, 2e-7, 2e-7)."""
+    U = (2 / 3, -1 / 3, 1 / 4)
+    a = O.Flow((16, 16, 16), U, T=np.float32)
+    O.mom_step(a, O.MultiLevelPoisson(a.p, a.mu0, a.sigma))
+    assert O.L2(a.u[..., 0] - np.float32(U[0])) < 2e-5
+    assert O.L2(a.u[..., 1] - np.float32(U[1])) < 1e-5 and O.L2(a.u[..., 2] - np.float32(U[2])) < 1e-5
