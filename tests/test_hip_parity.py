@@ -831,6 +831,31 @@ def test_sphere_in_accelerating_flow_added_mass_on_the_hip_path(radius, N):
     print(f"\nadded mass of the sphere R={radius} in {N}^3: force/(2/3 pi R^3) = {f}, peak speed {u.max() / u[1, 1, 1, 0]:.4f}")
 
 
+@pytest.mark.parametrize("T", TYPES)
+def test_viscous_decay_of_a_shear_wave_on_the_hip_path(T):
+    """tests/test_oracle_3d_structure.py: u_a = 0.5 sin(k x_b) in a fully periodic box decays by 1 - z + z^2/2 per Heun step,
+    z = nu dt (2 - 2 cos k) -- every (component, direction) pair of the diffusive flux, against the closed form (Float64 to
+    rounding, Float32 to a few ulp per step) and with the oracle's time steps."""
+    from test_oracle_3d_structure import shear_wave_case
+    n = 32
+    for a in range(3):
+        for b in range(3):
+            if a == b:
+                continue
+            kw, amplitude, k = shear_wave_case(a, b, n)
+            kw["T"] = T
+            so, sh = O.Simulation((n, n, n), (0, 0, 0), n, **kw), S.Simulation((n, n, n), (0, 0, 0), n, **kw)
+            u0 = S.to_host(sh.flow.u).astype(np.float64)
+            for _ in range(5):
+                O.sim_step(so)
+                S.sim_step(sh)
+            assert np.allclose(so.flow.dt, sh.flow.dt, rtol=10 * np.finfo(T).eps, atol=0), (a, b)
+            amp = amplitude(sh.flow.dt[:-1])
+            ins = (slice(1, -1),) * 3
+            err = np.abs(S.to_host(sh.flow.u).astype(np.float64)[ins] - amp * u0[ins]).max()
+            assert err < (1e-14 if T == np.float64 else 2e-6), (a, b, err)
+
+
 def test_ref_periodic_TGV():  # maintests.jl:232-253
     L = 64
     k = 2 * math.pi / L

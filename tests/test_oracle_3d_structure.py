@@ -264,3 +264,41 @@ def test_impulsive_flow_in_a_3d_box():
     O.mom_step(a, O.MultiLevelPoisson(a.p, a.mu0, a.sigma))
     assert O.L2(a.u[..., 0] - np.float32(U[0])) < 2e-5
     assert O.L2(a.u[..., 1] - np.float32(U[1])) < 1e-5 and O.L2(a.u[..., 2] - np.float32(U[2])) < 1e-5
+
+
+# ----------------------------------------------------------------------------- viscous decay of a shear wave
+def shear_wave_case(a, b, n=32, nu=0.5):
+    """u_a = 0.5 sin(k x_b), the other components 0, fully periodic: the convective term vanishes identically, the pressure
+    stays 0, and one Heun step of mom_step! (Flow.jl:153-169) multiplies the wave by 1 - z + z^2/2, z = nu * dt * (2 - 2 cos k)
+    (the three-point second difference of a sine).  Returns (kwargs of Simulation, amplitude factor for a list of dt)."""
+    import math
+    k = 2 * math.pi / n
+
+    def ulam(i, x):
+        return 0.5 * np.sin(k * x[b]) if i == a else np.zeros_like(x[0])
+
+    def amplitude(dts):
+        amp, lam = 1.0, nu * (2 - 2 * math.cos(k))
+        for dt in dts:
+            z = lam * dt
+            amp *= 1 - z + z * z / 2
+        return amp
+    return dict(U=1, ulam=ulam, nu=nu, T=np.float64, perdir=(0, 1, 2)), amplitude, k
+
+
+@pytest.mark.parametrize("a,b", [(0, 1), (0, 2), (1, 0), (1, 2), (2, 0), (2, 1)])
+def test_viscous_decay_of_a_shear_wave_follows_the_closed_form(a, b):
+    """every (component, direction) pair of the diffusive flux of conv_diff! and the Heun time stepping, Float64, to rounding;
+    the discrete decay is within 3e-4 of the continuous exp(-nu k^2 t) at 32 points per wave length"""
+    import math
+    n = 32
+    kw, amplitude, k = shear_wave_case(a, b, n)
+    s = O.Simulation((n, n, n), (0, 0, 0), n, **kw)
+    u0 = s.flow.u.copy(order="F")
+    for _ in range(5):
+        O.sim_step(s)
+    amp = amplitude(s.flow.dt[:-1])
+    ins = (slice(1, -1),) * 3
+    assert np.abs(s.flow.u[ins] - amp * u0[ins]).max() < 1e-14
+    t = float(np.sum(s.flow.dt[:-1]))
+    assert abs(amp - math.exp(-kw["nu"] * k * k * t)) < 3e-4 and amp < 0.98
