@@ -309,9 +309,9 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  *         (Flow.jl:144,139) are one pass over x, each rounding kept (default), 0 = two passes
  * key 18: 1 = conv_diff! evaluates each interior face flux once and shares it between the two cells (shared-flux LDS kernel
  *         on the tiles / planes whose y and z faces are all interior) (default), 0 = every cell gathers its six fluxes
- * key 19: 1 = on levels below 2^26 cells pcg! does not store z = A*eps: its update kernel is a second 7-point kernel over
- *         eps that forms the same A*eps again and applies r -= alpha*(A*eps) (default; 3-D vector kernels), 2 = on every
- *         level, 0 = the mult kernel always stores z
+ * key 19: 1 = on levels of 2^22 .. 2^26 cells pcg! does not store z = A*eps: its update kernel is a second 7-point kernel over
+ *         eps that forms the same A*eps again and applies r -= alpha*(A*eps) (default; 3-D vector kernels), 3 = on every
+ *         level below 2^26 cells, 2 = on every level, 0 = the mult kernel always stores z
  * key 20: 1 = the shared-flux conv_diff! kernel uses 64x8 tiles (512-thread workgroups) for Float32 (default), 0 = 64x4
  * key 22: 1 = inside wl_mom_step / wl_project (3-D, one device) z = div(u) is formed by the residual! kernel itself, the
  *         z array is neither written nor read (default), 0 = separate div pass

@@ -1241,10 +1241,13 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     // r -= alpha*(A*eps) in its epilogue.  Per iteration one array write (mult) and one array read (update) are replaced
     // by a second read of eps (with its halo rows and planes).  Measured: 512^3 mult 0.303 -> 0.224 ms but update
     // 0.344 -> 0.449 ms (the 7-point form of the update runs at 4.1 TB/s, with one or two rows per thread): no gain; 256^3 as the finest level: -2.5 % per
-    // step.  Default (1): levels below 2^26 cells; 2 = every level; 0 = never.
+    // step; levels of 128^3 cells and below are latency-bound and lose 5-10 % of a pcg! call to the heavier update kernel
+    // (tools/midlevels.py 19=3,0: 194 / 175, 110 / 101, 77 / 72 us).  Default (1): levels of 2^22 .. 2^26 cells; 3 = every level
+    // below 2^26; 2 = every level; 0 = never.
     bool zst = false;
     if constexpr (D == 3)
-        zst = (ctx().opt[19] >= 2 || (ctx().opt[19] == 1 && R.count() < (1L << 26))) && ctx().opt[5] != 0 && zrec && stencil7_ok<T>(p.g);
+        zst = (ctx().opt[19] == 2 || (ctx().opt[19] == 3 && R.count() < (1L << 26)) || (ctx().opt[19] == 1 && R.count() < (1L << 26) && R.count() >= (1L << 22))) &&
+              ctx().opt[5] != 0 && zrec && stencil7_ok<T>(p.g);
     // No finalize launches (wl_set_option(15), default on; single rank, default kernel forms): the dot products z.eps and
     // r.z' are finished by the NEXT kernel (every workgroup sums the <= 1024 partials and applies the scalar logic, Gate
     // kind 1..3), the state travels through st->slots; only the last update keeps its finalize (it publishes the state).
