@@ -324,6 +324,8 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  *         at 512^3, the streaming kernels gain 3-6 % from shorter z-chunks, the 7-point kernels do not)
  * key 30: 1 = consecutive marching kernels sweep their tiles in opposite directions, each XCD starting on the lines the
  *         kernel before it touched last (L2 / Infinity Cache) (default), 0 = always ascending.  Same bits either way.
+ * key 31: 1 = inside the one-workgroup bottom of the V-cycle (levels of <= 4096 cells) pcg! keeps its level in registers and
+ *         LDS for the whole call (default), 0 = every phase goes through global memory.  Same bits either way.
  * key 28: grid size of the velocity-correction kernel in units of 1024 workgroups (default 16; 4: 5 % slower at 512^3)
  * key 26: bound of a mailbox all-reduce's wait for a peer, in thousands of polls (default 40000, about a minute)
  * key 25: 1 = the shared-flux conv_diff! kernel uses 64x8 tiles for Float64 too (86.6 KB of LDS per workgroup), 0 = 64x4 (default)

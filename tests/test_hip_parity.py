@@ -337,6 +337,35 @@ def test_uniform_rows_are_skipped_exactly(T):
 
 
 @pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("dims", [(64, 32), (192, 64), (32, 32, 32), (64, 48, 16)])
+def test_coarse_tail_on_chip_bit_exact(T, dims):
+    """wl_set_option(31): inside the one-workgroup bottom of the V-cycle pcg! keeps its level in registers + LDS instead of
+    going through global memory between its phases.  Same expressions, same order of every sum: every field after several
+    steps (and every coarse level's x, r, eps, z after a V-cycle) is bit-identical with the switch on and off; levels of
+    1 and of 4 cells per thread, 2-D and 3-D."""
+    m = dims[1]
+    R, c = m / 8, m / 2 - 1
+    ubc = (1.0,) + (0.0,) * (len(dims) - 1)
+    runs = []
+    for on in (1, 0):
+        S.set_option(31, on)
+        try:
+            from waterlily_amd import body as B
+            s = S.Simulation(dims, ubc, 2 * R, nu=2 * R / 250, body=B.Sphere(c, R, len(dims)), T=T)
+            for _ in range(4):
+                S.sim_step(s, remeasure=False)
+        finally:
+            S.set_option(31, 1)
+        runs.append(s)
+    a, b = runs
+    assert a.pois.n == b.pois.n
+    assert torch.equal(a.flow.u, b.flow.u) and torch.equal(a.flow.p, b.flow.p)
+    for la, lb in zip(a.pois.levels[1:], b.pois.levels[1:]):
+        for k in ("x", "r", "eps", "z"):
+            assert torch.equal(getattr(la, k), getattr(lb, k)), k
+
+
+@pytest.mark.parametrize("T", TYPES)
 def test_pcg_without_stored_z_bit_exact(T):
     """wl_set_option(19): pcg!'s update kernel forms z = A*eps a second time (7-point kernel over eps) instead of reading
     the z the mult kernel stored.  Same expression on the same operands => x and r after the whole solver are

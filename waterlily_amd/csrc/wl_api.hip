@@ -313,7 +313,8 @@ template <class T, int D> static int mg_vcycle(wl_mg *m, int l, int *pcg_np = nu
         }
         if (tail) {
             Prof p(WL_K_SMOOTH, coarse.g.cells());
-            hipLaunchKernelGGL((k_coarse_vcycle<T, D>), dim3(1), dim3(CV_THREADS), 0, ctx().stream, ca);
+            if (ctx().opt[31]) hipLaunchKernelGGL((k_coarse_vcycle<T, D, true>), dim3(1), dim3(CV_THREADS), 0, ctx().stream, ca);
+            else hipLaunchKernelGGL((k_coarse_vcycle<T, D, false>), dim3(1), dim3(CV_THREADS), 0, ctx().stream, ca);
             WL_HIP(hipGetLastError());
         }
     }

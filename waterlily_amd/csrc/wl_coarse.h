@@ -169,20 +169,136 @@ template <class T, int D> __device__ void cv_pcg(const LevelT<T> &p, double *sm)
     }
 }
 
-template <class T, int D>
+// pcg!(p; it=6) with the level held ON CHIP (wl_set_option(31), default on): a thread keeps r, x, z, eps, iD and the face
+// coefficients of its <= 4 cells in registers for the whole call; only eps -- the one operand neighbours read -- lives in
+// LDS (ghost cells 0: non-periodic levels).  The phases of an iteration then wait for LDS (~0.1 us) instead of for stores
+// to reach L2 and come back (~1 us each, three per iteration).  Same per-cell expressions, same order of every sum as
+// cv_pcg => bit-identical x, r, z, eps (all four are written back at whichever exit is taken).
+constexpr int CV_CPT = CV_MAXCELLS / CV_THREADS;   // cells per thread
+constexpr int CV_LDS = 7936;                       // elements of the LDS copy of eps (with ghosts): 18^3 = 5832, 66^2 = 4356 fit
+template <int D> __device__ __forceinline__ bool cv_fits_lds(const G &g) {
+    return g.n[0] * g.n[1] * (D > 2 ? g.n[2] : 1) <= CV_LDS && cv_ncells<D>(g) <= CV_MAXCELLS;
+}
+// CPT: cells per thread the instance is built for (1: levels of <= 1024 cells, 4: up to 4096); LREG: the 2*D face coefficients of
+// a cell stay in registers too (else they are re-read each iteration: read-only, cache hits -- Float64 with four cells per
+// thread would spill 450 bytes per lane otherwise)
+template <class T, int D, int CPT, bool LREG> __device__ void cv_pcg_onchip(const LevelT<T> &p, double *sm, T *el) {
+    const G &g = p.g;
+    const int nc = cv_ncells<D>(g);
+    const int n0 = g.n[0], n1 = g.n[1];
+    const int ls[3] = {1, n0, n0 * n1};
+    const int ntot = n0 * n1 * (D > 2 ? g.n[2] : 1);
+    const T eps10 = (T)10 * Lim<T>::eps;
+    for (int q = threadIdx.x; q < ntot; q += CV_THREADS) el[q] = (T)0;
+    __syncthreads();
+    constexpr int NL = LREG ? CPT : 1;
+    long I[CPT];
+    int li[CPT];
+    bool has[CPT];
+    T r[CPT], x[CPT], z[CPT], e[CPT], id[CPT], lo[NL][D], hi[NL][D];
+    double acc = 0;
+#pragma unroll
+    for (int m = 0; m < CPT; ++m) {
+        const int c = (int)threadIdx.x + m * CV_THREADS;
+        has[m] = c < nc;
+        I[m] = 0; li[m] = 0;
+        r[m] = x[m] = z[m] = e[m] = id[m] = (T)0;
+        if (has[m]) {
+            int i, j, k;
+            I[m] = cv_cell<D>(g, c, i, j, k);
+            li[m] = i + n0 * (j + n1 * k);
+            r[m] = p.r[I[m]]; x[m] = p.x[I[m]]; id[m] = p.iD[I[m]];
+            if (LREG) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    lo[LREG ? m : 0][d] = p.L[I[m] + (long)d * g.sc];
+                    hi[LREG ? m : 0][d] = p.L[I[m] + g.s[d] + (long)d * g.sc];
+                }
+            }
+            const T v = r[m] * id[m];
+            z[m] = v; e[m] = v;
+            el[li[m]] = v;
+            acc += (double)r[m] * (double)v;
+        }
+    }
+    T rho = (T)cv_block_sum(acc, sm);          // (also a barrier: the LDS copy of eps is complete)
+    bool go = !((rho < 0 ? -rho : rho) < eps10);
+    for (int n = 1; go && n <= 6; ++n) {       // (every exit of pcg! is a `break`: one write-back below)
+        acc = 0;
+#pragma unroll
+        for (int m = 0; m < CPT; ++m)
+            if (has[m]) {
+                T l0[D], h0[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    l0[d] = LREG ? lo[LREG ? m : 0][d] : p.L[I[m] + (long)d * g.sc];
+                    h0[d] = LREG ? hi[LREG ? m : 0][d] : p.L[I[m] + g.s[d] + (long)d * g.sc];
+                }
+                T dg = 0;
+#pragma unroll
+                for (int d = 0; d < D; ++d) dg -= (l0[d] + h0[d]);
+                T s = e[m] * dg;
+#pragma unroll
+                for (int d = 0; d < D; ++d) s += el[li[m] - ls[d]] * l0[d] + el[li[m] + ls[d]] * h0[d];
+                z[m] = s;
+                acc += (double)s * (double)e[m];
+            }
+        const T alpha = rho / (T)cv_block_sum(acc, sm);
+        const double aa = (double)(alpha < 0 ? -alpha : alpha);
+        if (aa < 1e-2 || aa > 1e2) break;
+        const bool last = (n == 6);
+        acc = 0;
+#pragma unroll
+        for (int m = 0; m < CPT; ++m)
+            if (has[m]) {
+                x[m] += alpha * e[m];
+                const T rn = r[m] - alpha * z[m];
+                r[m] = rn;
+                if (!last) {
+                    const T zn = rn * id[m];
+                    z[m] = zn;
+                    acc += (double)rn * (double)zn;
+                }
+            }
+        if (last) break;
+        const T rho2 = (T)cv_block_sum(acc, sm);
+        if ((rho2 < 0 ? -rho2 : rho2) < eps10) break;
+        const T beta = rho2 / rho;
+#pragma unroll
+        for (int m = 0; m < CPT; ++m)
+            if (has[m]) {
+                e[m] = beta * e[m] + z[m];
+                el[li[m]] = e[m];             // (every read of the old eps happened before the two block sums above)
+            }
+        rho = rho2;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < CPT; ++m)
+        if (has[m]) { p.x[I[m]] = x[m]; p.r[I[m]] = r[m]; p.z[I[m]] = z[m]; p.eps[I[m]] = e[m]; }
+}
+
+template <class T, int D, bool ONCHIP>
 __global__ __launch_bounds__(CV_THREADS) void k_coarse_vcycle(CoarseArgs<T> a) {
     __shared__ double sm[CV_THREADS / 64];
+    __shared__ T el[ONCHIP ? CV_LDS : 1];
+    auto pcg = [&](const LevelT<T> &p) {
+        if (ONCHIP && cv_fits_lds<D>(p.g)) {                                     // (uniform in the workgroup)
+            if (cv_ncells<D>(p.g) <= CV_THREADS) cv_pcg_onchip<T, D, 1, true>(p, sm, el);
+            else cv_pcg_onchip<T, D, CV_CPT, sizeof(T) == 4>(p, sm, el);
+        } else cv_pcg<T, D>(p, sm);
+    };
     const int last = a.nlev - 1;
     for (int l = 0; l < last; ++l) {                 // down
         cv_smooth<T, D>(a.lev[l]);
         cv_restrict<T, D>(a.lev[l + 1], a.lev[l], a.lev[l].eps);
     }
     for (int l = last - 1; l >= 0; --l) {            // up
-        cv_pcg<T, D>(a.lev[l + 1], sm);
+        pcg(a.lev[l + 1]);
         __syncthreads();
         cv_prolong_inc<T, D>(a.lev[l], a.lev[l + 1]);
     }
-    cv_pcg<T, D>(a.lev[0], sm);
+    pcg(a.lev[0]);
 }
 
 }  // namespace wl

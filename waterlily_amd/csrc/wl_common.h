@@ -70,7 +70,7 @@ struct Mailbox {
 
 struct Ctx {
     Mailbox *mbox = nullptr;
-    int opt[32] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 1, 1, 1, 1, 1024, 0, 40000, 0, 16, 0, 1, 0};   // wl_set_option
+    int opt[32] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 1, 1, 1, 1, 1024, 0, 40000, 0, 16, 0, 1, 1};   // wl_set_option
     Comm *comm = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
