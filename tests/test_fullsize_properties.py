@@ -137,29 +137,6 @@ def test_projection_divergence_free_and_uniform_stream(S, flow, case):
         assert float((d.double() ** 2).sum()) < 2e-5 * ncell / 16 ** 3
 
 
-def _twin(dims, kind):
-    """the case's body on the product side (closures) and its volume"""
-    import bodies
-    m = min(dims)
-    if kind == "sphere":
-        R, c = m / 4, m / 2
-        return bodies.sphere(c, R).product, 2 * R, 4 / 3 * math.pi * R ** 3
-    c, R, r = m / 2, m / 4, m / 16
-    return bodies.torus(c, R, r).product, R, 2 * math.pi ** 2 * R * r ** 2
-
-
-def test_hydrostatic_force_on_the_body(S, case):
-    """maintests.jl:341-346 in 3-D at full size, through the whole product path: measure! on the device (band cells),
-    the |d|<=1 band rebuilt from them, wl_pforce.  p = y  =>  force = volume * e_y."""
-    dims, T, kind = case
-    body, L, vol = _twin(dims, kind)
-    sim = S.Simulation(dims, (1.0, 0.0, 0.0), L, body=body, T=T)
-    yy = torch.arange(dims[1] + 2, device="cuda", dtype=sim.flow.p.dtype) - 0.5
-    sim.flow.p.copy_(yy[None, :, None].expand(*(n + 2 for n in dims)))
-    force = S.pressure_force(sim)
-    assert np.sum(np.abs(force / vol - np.array([0, 1, 0]))) < 2e-3
-
-
 def test_rows_per_thread_same_bits(S, flow):
     """wl_set_option(4): the 7-point kernel with one or two rows per thread evaluates the same per-cell expressions:
     mult!, Jacobi!+increment! and the fused V-cycle smoother give bit-identical fields at full size."""
@@ -238,13 +215,22 @@ def test_traffic_saving_switches_do_not_change_a_bit(S, case):
         assert float((a[3] - c[3]).abs().max()) <= 1e-10 * float(a[3].abs().max())
 
 
-def test_two_steps_of_the_configuration(S, case):
+def test_hydrostatic_force_and_two_steps_of_the_configuration(S, case):
     """The BASELINE configuration itself (bench.py's set-up), two `sim_step!`s from the impulsive start: every solve
     converges in a few V-cycles (the reference's own multigrid bound is n <= 3 on its manufactured problems,
     maintests.jl:112-115; an impulsive start with a body takes one or two more on the first solve), leaves r.r below the
     solver tolerance and a velocity field that is divergence-free to it; forces, dt and u stay finite."""
     dims, T, kind = case
     sim = _bench_case(dims, T, kind)
+    # maintests.jl:341-346 in 3-D at full size first, through the whole product path (measure! on the device, the |d| <= 1 band
+    # rebuilt from its band cells, wl_pforce): p = y  =>  force = displaced volume * e_y
+    m = min(dims)
+    vol = 4 / 3 * math.pi * (m / 8) ** 3 if kind == "sphere" else 2 * math.pi ** 2 * (m / 4) * (m / 16) ** 2
+    yy = torch.arange(dims[1] + 2, device="cuda", dtype=sim.flow.p.dtype) - 0.5
+    sim.flow.p.copy_(yy[None, :, None].expand(*(n + 2 for n in dims)))
+    force = S.pressure_force(sim)
+    assert np.sum(np.abs(force / vol - np.array([0, 1, 0]))) < 2e-3, force / vol
+    sim.flow.p.zero_()
     S.sim_step(sim, remeasure=False)
     f1 = S.pressure_force(sim)
     S.sim_step(sim, remeasure=False)
