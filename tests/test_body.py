@@ -91,3 +91,28 @@ def test_nds_band_hydrostatic_2d():  # maintests.jl:341-346 geometry: integral o
     y = j - 0.5
     force = (y[:, None] * nds).sum(0)
     assert np.sum(np.abs(force / (math.pi * (N / 4) ** 2) - np.array([0, 1]))) < 2e-3
+
+
+def test_set_operations_on_parametric_bodies_keep_their_grouping():
+    """ParametricBody / Bodies operators: only a union of unions may be flattened into one left fold of the leaves;
+    a + (b - c), a | (b & c), a - (b + c), a & (b + c) must equal the nested AutoBody closures (AutoBody.jl:22-34)."""
+    D = 2
+    a, b, c = B.Sphere((10.0, 10.0), 4.0, D), B.Sphere((14.0, 10.0), 4.0, D), B.Sphere((8.0, 10.0), 3.0, D)
+    ca, cb, cc = (AutoBody(q.sdf) for q in (a, b, c))      # the same leaves as plain closures: operators nest
+    pts = torch.tensor([[11.0, 7.0, 9.0, 13.0, 16.0, 4.5], [10.0, 10.0, 11.5, 12.0, 10.0, 10.0]], dtype=torch.float64)
+    cases = [
+        (a + (b - c), ca + (cb - cc), False),
+        (a | (b & c), ca | (cb & cc), False),
+        (a - (b + c), ca - (cb + cc), False),
+        (a & (b + c), ca & (cb + cc), False),
+        (a + (b + c), ca + (cb + cc), True),     # union of unions: one native composite of three leaves
+        ((a - b) + c, (ca - cb) + cc, True),     # a left fold as written
+    ]
+    for got, want, native in cases:
+        assert np.allclose(B.sdf(got, pts).numpy(), B.sdf(want, pts).numpy(), atol=0, rtol=0)
+        assert (isinstance(got, B.Bodies) and B.is_native(got)) == native
+    # the advisor's two points: inside a ∩ c the wrong left folds (a ∪ b) − c and (a ∪ b) ∩ c differ from the nested bodies
+    assert float(B.sdf(a + (b - c), [11.0, 10.0])) == -3.0 and float(B.sdf(a | (b & c), [7.0, 10.0])) == -1.0
+    # a composite that stays native is described leaf by leaf, in order
+    d3 = (a + (b + c)).native_desc(0.0, D)
+    assert d3[0].count == 3 and [d3[l].op for l in range(3)] == [0, 0, 0]

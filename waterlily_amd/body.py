@@ -198,8 +198,12 @@ class Bodies(AutoBody):
         if isinstance(other, ParametricBody):
             return Bodies(self.bodies + [other], self.ops + [op])
         if isinstance(other, Bodies):
-            if op != "+" and len(other.bodies) > 1:     # (a - (b + c)) is not a left fold of the leaves: closures only
-                return {"-": AutoBody.__sub__, "&": AutoBody.__and__}[op](self, other)
+            # the leaves of `other` may only be appended to the left fold where that keeps the grouping: a single leaf, or a
+            # union of unions (associative).  a - (b + c), a & (b + c), a + (b - c), a + (b & c) ... are NOT left folds of
+            # the leaves: like the reference's AutoBody operators (AutoBody.jl:22-34) they nest, as closures
+            union_of_unions = op == "+" and all(self._OPS[o] == 0 for o in other.ops)
+            if len(other.bodies) > 1 and not union_of_unions:
+                return {"+": AutoBody.__add__, "-": AutoBody.__sub__, "&": AutoBody.__and__}[op](self, other)
             return Bodies(self.bodies + other.bodies, self.ops + [op] + other.ops)
         return {"+": AutoBody.__add__, "-": AutoBody.__sub__, "&": AutoBody.__and__}[op](self, other)
 
