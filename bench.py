@@ -168,28 +168,104 @@ def class_table(L):
     return names
 
 
-def main():
+C4_GRID = (1024, 1024, 512)   # BASELINE.json configs[3]: the strong-scaling case of the north star
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, default=512, help="cells per side (BASELINE config: 512)")
+    ap.add_argument("--size", type=int, default=None,
+                    help="cells per side of a cube (default at N=1: 512 = BASELINE configs[2]; N>1 without --size/--grid: "
+                         "1024x1024x512 = configs[3])")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-size", type=int, default=256, help="C2 of BASELINE.md section 3")
     ap.add_argument("--cpu-steps", type=int, default=8, help="timed steps of the C2 CPU baseline (256^3: about 0.5 s per step on 16 cores)")
     ap.add_argument("--cpu-c1-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--body", default="sphere", choices=["sphere", "donut", "cylinder", "tgv"],
-                    help="donut: BASELINE configs[4] (use with --dtype f64); cylinder: moving body, measure! every step (use with --dtype f64: the reference's Float32 solver stalls on it from 256^3, DESIGN.md section 5); tgv: no body")
+                    help="donut: BASELINE configs[4] (use with --dtype f64); cylinder: moving body, measure! every step (use with "
+                         "--dtype f64: in Float32 the C restatement of the reference's solver stalls on it from 256^3 -- not "
+                         "verified on WaterLily.jl, DESIGN.md section 5); tgv: no body")
     ap.add_argument("--layout", default="padded", choices=["padded", "dense"],
                     help="padded: rows 128-B aligned (default); dense: the reference's column-major layout (pitch N+2)")
+    ap.add_argument("--no-dense-leg", action="store_true", help="N=1: skip the extra 5-step run in the dense (drop-in) layout")
     ap.add_argument("--kernel", default=None, help="force the kernel class reported in `roofline`")
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "host"],
-                    help="multi-rank transport: rccl (one GPU per rank; a failing communicator is a non-zero exit) or host "
-                         "(explicit: gloo staging; lets ranks share a GPU, tests -- never an xGMI number)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "host", "loopback"],
+                    help="multi-rank transport: rccl (one GPU per rank; a failing communicator is a non-zero exit), host "
+                         "(explicit: gloo staging; lets ranks share a GPU, tests -- never an xGMI number) or loopback (ONE process "
+                         "plays rank --rank of --gpus: every exchange is a device copy of its own planes, the per-rank compute "
+                         "time of an N-GPU run measured on one GPU)")
+    ap.add_argument("--rank", type=int, default=None, help="--comm loopback: which rank's slab to run (default: the middle one)")
     ap.add_argument("--grid", type=int, nargs=3, default=None,
                     help="explicit GLOBAL grid nx ny nz (strong scaling, e.g. 1024 1024 512 = BASELINE configs[3])")
-    args = ap.parse_args()
+    ap.add_argument("--weak", action="store_true",
+                    help="N>1: weak scaling, every GPU keeps a size^3 slab (global size x size x size*N) instead of the fixed global grid")
+    ap.add_argument("--no-ref1", action="store_true",
+                    help="N>1 strong scaling: do not time the same global grid on ONE GPU (rank 0, after the N-GPU run) for `speedup_vs_1gpu`")
+    ap.add_argument("--ref1-steps", type=int, default=5)
+    return ap.parse_args(argv)
+
+
+def self_launch_cmd(ngpus, port, argv):
+    """the launcher line of the bench contract: one rank per GPU under torch.distributed.run"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes, relay what they
+    print (rank 0's JSON line) and leave with their status.  This parent never imports torch and never touches a GPU (a
+    process that has initialised the GPU must not exec / fork GPU work on this pool), and it does not exec."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 1)) // max(1, args.gpus))))
+    proc = subprocess.Popen(self_launch_cmd(args.gpus, port, argv), env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    if rc == 0 and line is None:
+        print("[bench] the ranks finished without printing a result line", file=sys.stderr)
+        rc = 4
+    return rc
+
+
+def make_sim(args, dims, T, dev, padded):
+    make = {"sphere": sphere, "donut": donut, "cylinder": moving_cylinder, "tgv": tgv}[args.body]
+    return make(dims, T, device=dev, padded=padded)
+
+
+def timed_steps(sim, steps, warmup, remeasure, sync):
+    """`warmup` untimed steps, then `steps` steps between two synchronisations: seconds"""
+    from waterlily_amd import sim as S
+    for _ in range(warmup):
+        S.sim_step(sim, remeasure=remeasure)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        S.sim_step(sim, remeasure=remeasure)
+    sync()
+    return time.perf_counter() - t0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.comm != "loopback":
+        raise SystemExit(self_launch(args, argv))          # (before torch is imported: the parent stays off the GPU)
 
     import torch
     import torch.distributed as dist
@@ -197,8 +273,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    loopback = args.comm == "loopback"
+    if loopback:
+        if world != 1:
+            raise SystemExit("--comm loopback is a one-process run")
+        world = max(1, args.gpus)
+        rank = (world // 2 if args.rank is None else args.rank)
+    elif world != max(1, args.gpus):
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started by a launcher with WORLD_SIZE={world}")
 
     from waterlily_amd import _lib
     from waterlily_amd import dist as wd
@@ -206,12 +288,13 @@ def main():
     L = _lib.lib()
     T = np.float32 if args.dtype == "f32" else np.float64
     tsz = np.dtype(T).itemsize
-    transport = "none" if world == 1 else ("rccl" if args.comm == "rccl" else "host-staging(gloo)")
-    if args.comm == "host":
+    transport = "none" if world == 1 else {"rccl": "rccl", "host": "host-staging(gloo)", "loopback": "loopback(device copies, one process)"}[args.comm]
+    if args.comm in ("host", "loopback"):
         local = local % max(1, torch.cuda.device_count())
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
-    if world > 1 and args.comm == "rccl":
+    real = world > 1 and not loopback                 # several processes
+    if real and args.comm == "rccl":
         # one process per GPU; the z axis is cut into `world` slabs, halos + scalar all-reduces run over RCCL (xGMI).
         # A communicator that cannot be created is a failed run (non-zero exit with the library's error text): a number
         # produced over any other transport would not be an xGMI measurement.
@@ -221,20 +304,30 @@ def main():
         except Exception as e:
             print(f"[bench] rank {rank}: RCCL communicator failed: {e} | {L.wl_last_error().decode()}", file=sys.stderr, flush=True)
             os._exit(3)   # (peers still inside ncclCommInitRank leave through dist.init_rccl's watchdog, WL_COMM_TIMEOUT, or the launcher)
-    elif world > 1:
+    elif real:
         dist.init_process_group("gloo")
         wd.init_host()
+    elif loopback and world > 1:
+        wd.init_loopback(rank, world)
     cr, cn = C.c_int(), C.c_int()
     _lib.check(L.wl_comm_rank(C.byref(cr), C.byref(cn)))
     if cn.value != world:
         raise SystemExit(f"libwlhip communicator has {cn.value} ranks, launcher has {world}")
-    m = args.size
-    # N=1: the BASELINE 512^3 cube.  N>1 (default): WEAK scaling -- every GPU keeps a 512x512x512 slab, i.e. the
-    # global grid is 512 x 512 x 512N; --grid gives an explicit global grid instead (strong scaling).
-    dims = tuple(args.grid) if args.grid else (m, m, m * world)
-    scaling = "strong" if args.grid else "weak"
-    make = {"sphere": sphere, "donut": donut, "cylinder": moving_cylinder, "tgv": tgv}[args.body]
-    sim = make(dims, T, device=dev, padded=(args.layout == "padded"))
+    if real and args.comm == "rccl" and wd.kind() != "rccl":
+        raise SystemExit("bench.py --comm rccl: the library's communicator is not RCCL")
+    # Workloads.  N=1: the BASELINE 512^3 cube (configs[2]).  N>1: STRONG scaling on BASELINE configs[3], 1024 x 1024 x 512
+    # (the north star's ">= 6x at 8 GPUs vs 1 GPU" case), unless --size (a cube, strong) / --grid (explicit) / --weak is given.
+    if args.grid:
+        dims, scaling = tuple(args.grid), "strong"
+    elif args.weak:
+        m = args.size or 512
+        dims, scaling = (m, m, m * world), "weak"
+    elif args.size or world == 1:
+        m = args.size or 512
+        dims, scaling = (m, m, m), ("strong" if world > 1 else "weak")
+    else:
+        dims, scaling = C4_GRID, "strong"
+    sim = make_sim(args, dims, T, dev, args.layout == "padded")
     remeasure = args.body == "cylinder"        # the moving body is re-measured every step (sim_step!'s default)
     ncell_global = int(np.prod(dims))
     ncell = ncell_global // world            # cells per rank: threshold for "finest level" launches
@@ -244,7 +337,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if real:
             dist.barrier()
 
     def timed_class(nm):
@@ -278,7 +371,7 @@ def main():
         S.sim_step(sim, remeasure=remeasure)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:  # MAX over ranks
+    if real:  # MAX over ranks
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.comm == "rccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -290,15 +383,16 @@ def main():
     mlups = ncell_global * args.steps / elapsed / 1e6
     n_uni, n_rows = S.uniform_rows(sim.pois, 0)
     phi = n_uni / max(1, n_rows)                       # share of x-rows whose L / iD loads are skipped
+    cube = dims[0] == dims[1] == dims[2]
     traffic_db = {}
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile) and not args.grid and world == 1:
+    if os.path.exists(tfile) and cube and world == 1 and args.layout == "padded":
         try:
             traffic_db = json.load(open(tfile))
         except Exception:
             traffic_db = {}
 
-    tkey = f"{m}^3/{args.dtype}" + ("" if args.body == "sphere" else "/" + args.body)   # case key of profiles/traffic.json
+    tkey = f"{dims[0]}^3/{args.dtype}" + ("" if args.body == "sphere" else "/" + args.body)   # case key of profiles/traffic.json
 
     def kernel_record(nm, launches, cells, total_ms):
         """bytes / rates of one kernel class from its launch count, summed cells and summed duration"""
@@ -332,31 +426,77 @@ def main():
     roof["per_class_ms_one_step"] = {k: {"launches": v["launches"], "ms": v["ms"]} for k, v in per_class.items()}
     sm = per_class.get("smooth")
     pr = per_class.get("prolongate")
+    Re = {"sphere": 3700, "tgv": 1600}.get(args.body, 1000)
+    what = ("uniform inflow, remeasure=false" if args.body in ("sphere", "donut") else
+            ("body moving through fluid at rest, remeasure=true (native measure! + changed-rows update! every step)" if remeasure else "no body"))
+    tag = ""
+    if args.dtype == "f32" and args.body == "sphere":
+        if dims == (512, 512, 512):
+            tag = " (BASELINE configs[2])"
+        elif dims == C4_GRID:
+            tag = " (BASELINE configs[3])"
+        elif dims == (256, 256, 256):
+            tag = " (BASELINE configs[1])"
+    if args.dtype == "f64" and args.body == "donut" and dims == (512, 512, 512):
+        tag = " (BASELINE configs[4])"
+    workload = (f"3D {args.body} {dims[0]}x{dims[1]}x{dims[2]}, Re={Re}, {args.dtype}, {what}" + (", dense layout" if args.layout == "dense" else "") + tag
+                + ("" if world == 1 else (f", rank {rank} of {world} z-slabs alone on one GPU (loopback exchanges)" if loopback else f", z-slabs over {world} GPUs")))
     out = {
         "metric": "MLUPS (cell-updates/s) per sim_step!, 3D sphere", "value": mlups, "unit": "MLUPS",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "n_gpus": 1 if loopback else world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"3D {args.body} {dims[0]}x{dims[1]}x{dims[2]}, Re={ {'sphere': 3700, 'tgv': 1600}.get(args.body, 1000)}, {args.dtype}, "
-                               + ("uniform inflow, remeasure=false" if args.body in ("sphere", "donut") else
-                                  ("body moving through fluid at rest, remeasure=true (native measure! + changed-rows update! every step)" if remeasure else "no body")) + (", dense layout" if args.layout == "dense" else "") + (" (BASELINE configs[2])" if world == 1 and not args.grid and m == 512
-                                                     and args.dtype == "f32" and args.body == "sphere" else "" if world == 1 else
-                                                     f", z-slabs over {world} GPUs"),
+        "config": {"workload": workload, "layout": args.layout,
                    "transport": transport, "comm_ranks": cn.value,
                    "scalar_allreduce": ("none" if world == 1 else ("mailbox(pinned host memory)" if wd.mailbox_active() else
-                                                                   ("ncclAllReduce" if args.comm == "rccl" else "host callbacks"))),
+                                                                   ("ncclAllReduce" if args.comm == "rccl" else ("device scaling" if loopback else "host callbacks")))),
                    "collectives_last_step": S.comm_counts() if world > 1 else None,
                    "vcycles_per_solve": vcycles[:6], "mean_vcycles_per_step": float(np.sum(vcycles)) / args.steps},
         "roofline": roof,
         "smoother": kernel_record("smooth", sm["launches"], sm["cells"], sm["ms"]) if sm else None,
         "prolong_increment": kernel_record("prolongate", pr["launches"], pr["cells"], pr["ms"]) if pr else None,
     }
+    if loopback and world > 1:
+        # value = what `world` such ranks would deliver if nothing but this rank's own work limited them (no wire time)
+        out["loopback"] = {"rank": rank, "of": world, "per_rank_ms_per_step": out["ms_per_step"],
+                           "note": "one process plays one rank of the N-GPU run: its slab, its split launches, its reductions; every "
+                                   "exchange is a device copy, every all-reduce a scaling kernel -- compute + launch time of a rank, no wire"}
+    del sim
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_dense_leg and args.layout == "padded":
+        # the layout the reference-side binding hands over (julia/WaterLilyHIPNativeExt.jl: dense column-major, pitch N+2)
+        try:
+            sd = make_sim(args, dims, T, dev, False)
+            k = min(5, args.steps)
+            td = timed_steps(sd, k, 2, remeasure, sync)
+            out["layout_dense"] = {"ms_per_step": td / k * 1e3, "value": ncell_global * k / td / 1e6, "unit": "MLUPS", "steps": k, "warmup": 2,
+                                   "vs_padded": (td / k) / (elapsed / args.steps)}
+            del sd
+            gc.collect()
+            torch.cuda.empty_cache()
+        except Exception as e:                                    # the headline number stands on its own
+            out["layout_dense"] = {"error": str(e)[:200]}
+    if real:
+        wd.finalize()
+        dist.destroy_process_group()          # (before rank 0's one-GPU leg: nobody waits in a collective for it)
+    if real and scaling == "strong" and not args.no_ref1 and rank == 0:
+        # the same global grid on ONE GPU (rank 0's, the communicator is gone): the denominator of the strong-scaling claim
+        try:
+            s1 = make_sim(args, dims, T, dev, args.layout == "padded")
+            k = max(1, args.ref1_steps)
+            t1 = timed_steps(s1, k, 2, remeasure, torch.cuda.synchronize)
+            out["one_gpu"] = {"ms_per_step": t1 / k * 1e3, "value": ncell_global * k / t1 / 1e6, "unit": "MLUPS", "steps": k, "warmup": 2,
+                              "note": "same grid, same build, one GPU (rank 0 after the N-GPU run)"}
+            out["speedup_vs_1gpu"] = (t1 / k) / (elapsed / args.steps)
+            del s1
+        except Exception as e:
+            out["one_gpu"] = {"error": str(e)[:200]}
+            out["speedup_vs_1gpu"] = None
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps, args.cpu_c1_steps)
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        wd.finalize()
-        dist.destroy_process_group()
+    if rank == 0 or loopback:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

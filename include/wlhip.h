@@ -83,6 +83,10 @@ typedef int (*wl_host_allreduce_fn)(void *user, double *vals, int n, int op);
 typedef int (*wl_host_allgather_fn)(void *user, void *buf, int64_t bytes);
 int wl_comm_init_host(int rank, int nranks, wl_host_sendrecv_fn sr, wl_host_allreduce_fn ar, wl_host_allgather_fn ag,
                       void *user);
+/* Measurement: ONE process plays rank `rank` of an `nranks`-way z-slab run on one GPU.  Its neighbours are taken to be copies of
+ * itself (the planes it would send up arrive from below and vice versa, as device copies), a sum over the ranks is nranks times
+ * the local value, an all-gather repeats the local segment: the compute and launch time of a rank, without a wire. */
+int wl_comm_init_loopback(int rank, int nranks);
 /* Mailbox all-reduce for the run's scalars (dot products, CFL maximum, force sums): after the communicator exists every rank
  * of the NODE opens the same POSIX shared-memory object `shm_name` ("/name"); the one rank that passes create != 0 must
  * have returned before the others call (the host orders it: create on rank 0, barrier, open elsewhere, barrier, then rank 0
@@ -109,15 +113,19 @@ int wl_bc_per(wl_dtype t, const wl_grid *g, void *a, int perdir_mask);
 int wl_exit_bc(wl_dtype t, const wl_grid *g, void *u, const void *u0, const double U[3], double dt);
 /* L2(a) = sum(abs2, inside(a))        src/util.jl:68 (ext/WaterLilyAMDGPUExt.jl:24) */
 int wl_L2_inside(wl_dtype t, const wl_grid *g, const void *a, double *out);
-/* dot / sum / maximum over inside(a): LinearAlgebra.dot, Base.sum, Base.maximum as used at
- * src/Poisson.jl:94,126,131,137,146 and src/Flow.jl:174 (ghost entries are zero there) */
+/* dot / sum / maximum over the WHOLE array, ghost cells included: LinearAlgebra.dot, Base.sum, Base.maximum as used at
+ * src/Poisson.jl:94,126,131,137,146 and src/Flow.jl:174 (z-slab runs: over the planes the ranks own, all-reduced) */
 int wl_dot(wl_dtype t, const wl_grid *g, const void *a, const void *b, double *out);
 int wl_sum(wl_dtype t, const wl_grid *g, const void *a, double *out);
 int wl_max(wl_dtype t, const wl_grid *g, const void *a, double *out);
 
 /* ------------------------------------------------------------------ Flow.jl operators */
-/* conv_diff!(r,u,Phi;nu,perdir)       src/Flow.jl:36-60  (gather form: no Phi scratch needed) */
-int wl_conv_diff(wl_dtype t, const wl_grid *g, void *r, const void *u, double nu, int perdir_mask);
+/* conv_diff!(r,u,Phi;nu,perdir)       src/Flow.jl:36-60.  The kernels are in gather form and need no scratch; what the
+ * reference's scatter form LEAVES in Phi where a later whole-array reduction reads it -- the top ghost cells (its loops run
+ * over inside_u, util.jl:55-57: "top ghost included"; Phi is flow.sigma inside mom_step!, src/Flow.jl:157,164) -- is written
+ * to Phi when Phi != NULL: each such cell gets the flux of the last (i,j) loop pair whose range holds it.  Interior cells of
+ * Phi (scratch the reference overwrites before reading) are not touched. */
+int wl_conv_diff(wl_dtype t, const wl_grid *g, void *r, const void *u, void *Phi, double nu, int perdir_mask);
 /* accelerate!(r,dt,g,U)               src/Flow.jl:68-73  (host evaluates g(i,t)+dU_i/dt) */
 int wl_accelerate(wl_dtype t, const wl_grid *g, void *r, const double acc[3]);
 /* BDIM!(a)                            src/Flow.jl:131-135 */
@@ -349,6 +357,9 @@ int wl_prof_select(int kclass, int64_t min_cells);
 int wl_prof_reset(void);
 /* launches / cells processed per class since the last reset (all classes, all levels) */
 int wl_prof_counts(int kclass, int64_t *launches, int64_t *cells);
+/* device and pinned-host allocations the library itself has made since it was loaded (count, bytes): a steady wl_mom_step makes
+ * none (the reference bounds mom_step!'s allocations the same way, test/alloctest.jl:17-27) */
+int wl_prof_allocs(int64_t *count, int64_t *bytes);
 /* number of stencil launches since start-up that were split to overlap a z-slab halo exchange (comm stream) */
 int wl_prof_overlapped(int64_t *count);
 /* collectives issued by this rank since the last wl_prof_reset (z-slab runs; all zero without a communicator):

@@ -78,8 +78,8 @@ Base.getindex(a::HIPArray, I::CartesianIndex) = a[Tuple(I)...]
 Base.setindex!(a::HIPArray, v, I::CartesianIndex) = (a[Tuple(I)...] = v)
 
 # ---- Base / LinearAlgebra generics the path calls on arrays (SURVEY.md 8b): device reductions where the library has one.
-# wl_dot / wl_sum / wl_max reduce over inside(a); every array the path reduces (Poisson.jl:94,126-146; Flow.jl:174) has
-# zero ghost entries there, see DESIGN.md section 7.1.  Vector fields (trailing component axis) take the host route.
+# wl_dot / wl_sum / wl_max reduce over the WHOLE array, ghost cells included, like the Base generics they stand in for
+# (Poisson.jl:94,126-146; Flow.jl:174).  Vector fields (trailing component axis) take the host route.
 # (the function name of a `ccall` has to be a constant: one method per entry point, generated here)
 for (fn, sym) in ((:lib_sum, :wl_sum), (:lib_max, :wl_max))
     @eval function $fn(a::HIPArray{T}) where T
@@ -148,9 +148,9 @@ function apply!(f, c::HIPArray)                                                 
 end
 
 # ---------------------------------------------------------------------------------------------- Flow.jl operators
-conv_diff!(r::HIPArray{T}, u::HIPArray{T}, Φ; ν=0.1, perdir=()) where T =                       # src/Flow.jl:36-60
-    chk(ccall((:wl_conv_diff, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint),
-              dtype(T), grid(u, ndims(u) - 1), r.ptr, u.ptr, ν, mask(perdir)))
+conv_diff!(r::HIPArray{T}, u::HIPArray{T}, Φ::HIPArray{T}; ν=0.1, perdir=()) where T =          # src/Flow.jl:36-60
+    chk(ccall((:wl_conv_diff, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint),
+              dtype(T), grid(u, ndims(u) - 1), r.ptr, u.ptr, Φ.ptr, ν, mask(perdir)))         # (Φ's top ghost cells: what the scatter form leaves)
 BDIM!(a::Flow{N,T,<:HIPArray}) where {N,T} =                                                    # src/Flow.jl:131-135
     chk(ccall((:wl_bdim, lib), Cint, (Cint, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
               Ptr{Cvoid}, Cdouble), dtype(T), grid(a.p), a.u.ptr, a.u⁰.ptr, a.f.ptr, a.V.ptr, a.μ₀.ptr, a.μ₁.ptr, a.Δt[end]))

@@ -26,14 +26,6 @@ typedef struct wlo_grid {
 
 #define WLO_MAXLEV 16
 
-/* 0 (default): reductions exactly where the reference takes them -- LinearAlgebra.dot and maximum over the
- * WHOLE arrays, ghosts included (src/Poisson.jl:126-146, src/Flow.jl:174).  1: over inside() only, which is
- * what the HIP path computes.  The two differ only through ghost entries that hold stale scratch (sigma is
- * also conv_diff!'s Phi) multiplied by periodic copies; tests use the switch to show that this is the ONLY
- * difference in periodic runs (deliberate deviations). */
-static int wlo_interior_reductions = 0;
-void wlo_set_interior_reductions(int on) { wlo_interior_reductions = on; }
-
 /* middle eigenvalue of a symmetric 3x3 matrix (closed form): lambda2 = eigvals(Hermitian(S^2+Omega^2))[2] */
 static double wlo_sym3_mid_eig(double a00, double a01, double a02, double a11, double a12, double a22) {
     const double p1 = a01 * a01 + a02 * a02 + a12 * a12;

@@ -128,11 +128,6 @@ def _declare(L: C.CDLL) -> None:
         f("wlo_t_phiuR", d, vp, lg, d)
 
 
-def set_interior_reductions(on: bool) -> None:
-    """see wl_oracle.c: False = faithful whole-array reductions (default), True = inside() only"""
-    lib().wlo_set_interior_reductions(int(on))
-
-
 def _fn(name: str, T):
     return getattr(lib(), name + _suf(T))
 

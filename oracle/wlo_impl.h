@@ -137,20 +137,8 @@ T SUF(wlo_dot)(const T *a, const T *b, long n) {
     for (long q = 0; q < n; ++q) s += (double)a[q] * (double)b[q];
     return (T)s;
 }
-/* dot used by pcg!/L2: whole array (faithful, default) or inside() only (wlo_interior_reductions=1) */
-static T SUF(dot_g)(const T *a, const T *b, const wlo_grid *g) {
-    if (!wlo_interior_reductions) return SUF(wlo_dot)(a, b, g->ncell);
-    double s = 0;
-    const int k0 = g->D > 2 ? 1 : 0, k1 = g->D > 2 ? g->n[2] - 2 : 0;
-#pragma omp parallel for reduction(+ : s) schedule(static) if (g->ncell > 16384)
-    for (int k = k0; k <= k1; ++k)
-        for (int j = 1; j <= g->n[1] - 2; ++j)
-            for (int i = 1; i <= g->n[0] - 2; ++i) {
-                const long I = (long)i + g->s[1] * j + g->s[2] * k;
-                s += (double)a[I] * (double)b[I];
-            }
-    return (T)s;
-}
+/* dot used by pcg!/L2: LinearAlgebra.dot over the whole arrays, ghost entries included */
+static T SUF(dot_g)(const T *a, const T *b, const wlo_grid *g) { return SUF(wlo_dot)(a, b, g->ncell); }
 static T SUF(max_all)(const T *a, long n) {
     T m = a[0];
 #pragma omp parallel for reduction(max : m) schedule(static) if (n > 16384)
@@ -348,16 +336,6 @@ double SUF(wlo_cfl)(T *sigma, const T *u, const wlo_grid *g, double nu_) {
         sigma[I] = (T)s;
     });
     T m = SUF(max_all)(sigma, nc); /* maximum over the WHOLE array (ghosts keep stale Phi) */
-    if (wlo_interior_reductions) {
-        m = sigma[g->s[1] + (g->D > 2 ? g->s[2] : 0) + 1];
-        const int k0 = g->D > 2 ? 1 : 0, k1 = g->D > 2 ? g->n[2] - 2 : 0;
-        for (int k = k0; k <= k1; ++k)
-            for (int j = 1; j <= g->n[1] - 2; ++j)
-                for (int i = 1; i <= g->n[0] - 2; ++i) {
-                    const T v = sigma[(long)i + g->s[1] * j + g->s[2] * k];
-                    m = v > m ? v : m;
-                }
-    }
     const T d = (T)1 / (m + (T)5 * (T)nu_);
     return (double)(d < (T)10 ? d : (T)10);
 }

@@ -26,8 +26,10 @@ def _shift(f):
 
 def sphere(center, radius):
     """circle (2-D) / sphere (3-D): sqrt(sum(abs2, x .- center)) - radius"""
-    return Twin(AutoBody(lambda x, t: norm2(x - center) - radius), G.Body(G.Sphere(center, radius)),
-                lambda D: B.Sphere(center, radius, D))
+    def sdf(x, t):   # (center: one number for every axis, or one per axis)
+        c = center if not hasattr(center, "__len__") else torch.as_tensor(center, dtype=x.dtype, device=x.device)[:, None]
+        return norm2(x - c) - radius
+    return Twin(AutoBody(sdf), G.Body(G.Sphere(center, radius)), lambda D: B.Sphere(center, radius, D))
 
 
 def cylinder(center, radius, D=3):

@@ -97,6 +97,7 @@ def lib() -> C.CDLL:
         "wl_comm_unique_id": (i, [vp]),
         "wl_comm_init_rccl": (i, [vp, i, i]),
         "wl_comm_init_host": (i, [i, i, SENDRECV_FN, ALLREDUCE_FN, ALLGATHER_FN, vp]),
+        "wl_comm_init_loopback": (i, [i, i]),
         "wl_comm_mailbox": (i, [C.c_char_p, i]),
         "wl_comm_mailbox_off": (i, []),
         "wl_comm_mailbox_active": (i, [ip]),
@@ -111,7 +112,7 @@ def lib() -> C.CDLL:
         "wl_dot": (i, [i, gp, vp, vp, dp]),
         "wl_sum": (i, [i, gp, vp, dp]),
         "wl_max": (i, [i, gp, vp, dp]),
-        "wl_conv_diff": (i, [i, gp, vp, vp, d, i]),
+        "wl_conv_diff": (i, [i, gp, vp, vp, vp, d, i]),
         "wl_accelerate": (i, [i, gp, vp, dp]),
         "wl_bdim": (i, [i, gp, vp, vp, vp, vp, vp, vp, d]),
         "wl_scale_u": (i, [i, gp, vp, d]),
@@ -155,6 +156,7 @@ def lib() -> C.CDLL:
         "wl_prof_reset": (i, []),
         "wl_prof_overlapped": (i, [C.POINTER(i64)]),
         "wl_prof_counts": (i, [i, C.POINTER(i64), C.POINTER(i64)]),
+        "wl_prof_allocs": (i, [C.POINTER(i64), C.POINTER(i64)]),
         "wl_prof_comm": (i, [C.POINTER(i64)]),
         "wl_prof_reset_comm": (i, []),
         "wl_prof_allreduce_us": (i, [i, dp]),

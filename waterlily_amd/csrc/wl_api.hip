@@ -67,7 +67,7 @@ struct HostComm : Comm {
         if (b <= cap) return 0;
         if (pin) (void)hipHostFree(pin);
         cap = b * 2;
-        return (int)hipHostMalloc((void **)&pin, cap, hipHostMallocDefault);
+        return (int)wl_host_alloc((void **)&pin, cap, hipHostMallocDefault);
     }
     int do_allreduce(double *dev, int n, int op) override {
         double v[8];
@@ -99,6 +99,30 @@ struct HostComm : Comm {
         if (ag(user, pin, (int64_t)bytes)) return fail(WL_E_STATE, "host allgather callback failed", __FILE__, __LINE__);
         WL_HIP(hipMemcpyAsync(buf, pin, tot, hipMemcpyHostToDevice, ctx().stream));
         WL_HIP(hipStreamSynchronize(ctx().stream));
+        return 0;
+    }
+};
+
+// Loopback twin (measurement: bench.py --comm loopback): ONE process plays rank `rank` of `size`.  Its neighbours are taken to be
+// copies of itself (a periodic stack of this slab): the planes it would send up arrive as the planes from below and vice
+// versa (device copies on the stream), a sum over the ranks is `size` times the local value, an all-gather repeats the local
+// segment.  Every kernel, split launch and reduction of a rank of the N-GPU run is issued; nothing waits for a wire.
+__global__ void k_loop_scale(double *v, int n, double f) { if ((int)threadIdx.x < n) v[threadIdx.x] *= f; }
+struct LoopComm : Comm {
+    int do_allreduce(double *dev, int n, int op) override {
+        if (op != 0) return 0;
+        hipLaunchKernelGGL(k_loop_scale, dim3(1), dim3(64), 0, ctx().stream, dev, n, (double)size);
+        return (int)hipGetLastError();
+    }
+    int do_sendrecv(const void *slo, void *rlo, const void *shi, void *rhi, size_t bytes, int, int) override {
+        const void *from_below = shi ? shi : slo, *from_above = slo ? slo : shi;
+        if (rlo && from_below) WL_HIP(hipMemcpyAsync(rlo, from_below, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+        if (rhi && from_above) WL_HIP(hipMemcpyAsync(rhi, from_above, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+        return 0;
+    }
+    int do_allgather(void *buf, size_t bytes) override {
+        for (int r = 0; r < size; ++r)
+            if (r != rank) WL_HIP(hipMemcpyAsync((char *)buf + (size_t)r * bytes, (const char *)buf + (size_t)rank * bytes, bytes, hipMemcpyDeviceToDevice, ctx().stream));
         return 0;
     }
 };
@@ -167,10 +191,10 @@ struct Scratch {
     State *st = nullptr;         // device
     State *hst = nullptr;        // pinned host mirror
     int init() {
-        WL_HIP(hipMalloc((void **)&partials, sizeof(double) * 4 * WL_MAXB));
-        WL_HIP(hipMalloc((void **)&st, sizeof(State)));
+        WL_HIP(wl_dev_alloc((void **)&partials, sizeof(double) * 4 * WL_MAXB));
+        WL_HIP(wl_dev_alloc((void **)&st, sizeof(State)));
         WL_HIP(hipMemset(st, 0, sizeof(State)));
-        WL_HIP(hipHostMalloc((void **)&hst, sizeof(State), hipHostMallocDefault));
+        WL_HIP(wl_host_alloc((void **)&hst, sizeof(State), hipHostMallocDefault));
         memset(hst, 0, sizeof(State));
         return 0;
     }
@@ -219,7 +243,7 @@ struct wl_mg {
         for (int l = 0; l < nlev; ++l) {
             const wl_grid &g = lev[l].g;
             if (g.D != 3) continue;
-            WL_HIP(hipMalloc(&rowc[l], (size_t)g.n[1] * (size_t)g.n[2] * RC_N * es));
+            WL_HIP(wl_dev_alloc(&rowc[l], (size_t)g.n[1] * (size_t)g.n[2] * RC_N * es));
         }
         return 0;
     }
@@ -355,7 +379,7 @@ template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, in
     while (n < itmx) {
         int pre = -1;
         if (m->nlev > 1) WL_TRY((mg_vcycle<T, D>(m, 0, &pre)));
-        WL_TRY((op_pcg<T, D>(p, 6, m->permask, m->sc.partials, m->sc.st, true, pre)));
+        WL_TRY((op_pcg<T, D>(p, 6, m->permask, m->sc.partials, m->sc.st, true, pre, true)));   // (level 1: z ≡ flow.σ)
         WL_TRY((op_L2<T, D>(p, m->sc.partials, m->sc.st, true)));
         WL_TRY(m->sc.fetch());
         ++n;
@@ -424,6 +448,10 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     const XBc<T> xbc{(D == 3 && d.perdir_mask == 0 && ctx().opt[7] && ctx().opt[23]) ? 1 : 0, d.exitBC ? 1 : 0, (T)U[0]};
     bool xd = false;
     WL_TRY((op_conv_diff<T, D, true, true>(g, f, u, d.nu, d.perdir_mask, nullptr, V, dt, gp, gp != nullptr, u0)));
+    // σ's top ghost cells: the flux scratch Φ the reference's conv_diff! leaves there (Flow.jl:157), read by its whole-array
+    // z⋅ϵ in the projection that follows (periodic runs only: elsewhere ϵ's ghosts are zero) and by maximum(a.σ) in CFL --
+    // which sees the corrector's values, so a non-periodic run skips the predictor's.
+    if (d.perdir_mask != 0) WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, u, d.nu, d.perdir_mask)));
     WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd)));   // + exchange of f (overlapped)
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
     if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, u, u0, U, dt, a->sc.partials, a->sc.st)));
@@ -434,6 +462,7 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
     // corrector (:164-167); the 2-plane exchange of u is issued inside op_conv_diff (overlapped with its inner planes)
     WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr, nullptr, true)));
+    WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, u, d.nu, d.perdir_mask)));   // (Flow.jl:164: Φ of the corrector)
     WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
     WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true, chain, nullptr, &xbc, &xd)));
@@ -451,13 +480,13 @@ template <class T, int D> static int red_L2(const G &g, const T *a, Scratch &S) 
 }
 template <class T, int D> static int red_dot(const G &g, const T *a, const T *b, Scratch &S) {
     return op_reduce<T, D>(g, WL_K_DOT, RED_SUM, 0.0, [=] __device__(long I) { return (double)a[I] * (double)b[I]; },
-                           S.partials, S.st, 0);
+                           S.partials, S.st, 0, true);
 }
 template <class T, int D> static int red_sum(const G &g, const T *a, Scratch &S) {
-    return op_reduce<T, D>(g, WL_K_DOT, RED_SUM, 0.0, [=] __device__(long I) { return (double)a[I]; }, S.partials, S.st, 0);
+    return op_reduce<T, D>(g, WL_K_DOT, RED_SUM, 0.0, [=] __device__(long I) { return (double)a[I]; }, S.partials, S.st, 0, true);
 }
 template <class T, int D> static int red_max(const G &g, const T *a, Scratch &S) {
-    return op_reduce<T, D>(g, WL_K_DOT, RED_MAX, -1e300, [=] __device__(long I) { return (double)a[I]; }, S.partials, S.st, 0);
+    return op_reduce<T, D>(g, WL_K_DOT, RED_MAX, -1e300, [=] __device__(long I) { return (double)a[I]; }, S.partials, S.st, 0, true);
 }
 template <class T, int D>
 static int bdim_full(const G &g, T *u, const T *u0, T *f, const T *V, const T *mu0, const T *mu1, double dt) {
@@ -620,9 +649,9 @@ static int flow_compact_busy(wl_flow *a, const G &g, int D) {
     if (list.size() > a->busy_cap) {
         if (a->busy) (void)hipFree(a->busy);
         a->busy_cap = list.size() * 2 + 64;
-        WL_HIP(hipMalloc((void **)&a->busy, a->busy_cap * sizeof(int)));
+        WL_HIP(wl_dev_alloc((void **)&a->busy, a->busy_cap * sizeof(int)));
     }
-    if (!a->busy) { a->busy_cap = 64; WL_HIP(hipMalloc((void **)&a->busy, a->busy_cap * sizeof(int))); }
+    if (!a->busy) { a->busy_cap = 64; WL_HIP(wl_dev_alloc((void **)&a->busy, a->busy_cap * sizeof(int))); }
     if (!list.empty()) WL_HIP(hipMemcpyAsync(a->busy, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, ctx().stream));
     WL_HIP(hipStreamSynchronize(ctx().stream));
     a->nbusy = (int)list.size();
@@ -650,11 +679,11 @@ static BodyDev body_dev(const wl_body_desc *bodies) {
 }
 static int measure_alloc(wl_flow *a, size_t nrows) {
     if (a->rowcount) return 0;
-    WL_HIP(hipMalloc((void **)&a->rowcount, nrows * sizeof(int)));
-    WL_HIP(hipMalloc((void **)&a->rowoff, (nrows + 1) * sizeof(long)));
-    WL_HIP(hipMalloc((void **)&a->touched, nrows));
-    WL_HIP(hipMalloc((void **)&a->prev, nrows));
-    WL_HIP(hipMalloc((void **)&a->changed, nrows));
+    WL_HIP(wl_dev_alloc((void **)&a->rowcount, nrows * sizeof(int)));
+    WL_HIP(wl_dev_alloc((void **)&a->rowoff, (nrows + 1) * sizeof(long)));
+    WL_HIP(wl_dev_alloc((void **)&a->touched, nrows));
+    WL_HIP(wl_dev_alloc((void **)&a->prev, nrows));
+    WL_HIP(wl_dev_alloc((void **)&a->changed, nrows));
     return 0;
 }
 template <class T, int D> static int measure_rows(wl_flow *a, const wl_body_desc *body, double eps, int64_t *nband) {
@@ -747,6 +776,11 @@ template <class T, int D> static int restrictL_full(const G &A, T *a, const G &B
     return coarse_L_finish<T, D>(A, a, B, permask);
 }
 
+template <class T, int D> static int conv_diff_phi(const G &g, T *r, const T *u, T *Phi, double nu, int permask) {
+    WL_TRY((op_conv_diff<T, D, false>(g, r, u, nu, permask, nullptr, nullptr, 0.0, nullptr, false)));
+    return Phi ? op_sigma_ghosts<T, D>(g, Phi, u, nu, permask) : 0;
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -784,6 +818,14 @@ int wl_comm_init_host(int rank, int nranks, wl_host_sendrecv_fn sr, wl_host_allr
     ctx().comm = c;
     return 0;
 }
+int wl_comm_init_loopback(int rank, int nranks) {
+    if (ctx().comm) return fail(WL_E_STATE, "communicator already initialised", __FILE__, __LINE__);
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(WL_E_ARG, "wl_comm_init_loopback: bad rank", __FILE__, __LINE__);
+    LoopComm *c = new LoopComm();
+    c->rank = rank; c->size = nranks;
+    ctx().comm = c;
+    return 0;
+}
 static void mailbox_release() {
     Mailbox *mb = ctx().mbox;
     if (!mb) return;
@@ -816,7 +858,7 @@ int wl_comm_mailbox(const char *shm_name, int create) {
     mb->host = (MboxSlot *)p;
     void *dp = nullptr;
     e = hipHostGetDevicePointer(&dp, p, 0);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&mb->err_host, sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) e = wl_host_alloc((void **)&mb->err_host, sizeof(int), hipHostMallocMapped);
     if (e == hipSuccess) { *mb->err_host = 0; e = hipHostGetDevicePointer((void **)&mb->err_dev, mb->err_host, 0); }
     if (e != hipSuccess) {
         (void)hipHostUnregister(p); munmap(p, bytes);
@@ -902,7 +944,7 @@ int wl_device_count(int *n) {
 int wl_set_device(int dev) { WL_HIP(hipSetDevice(dev)); return 0; }
 int wl_set_stream(void *s) { ctx().stream = (hipStream_t)s; return 0; }
 int wl_sync(void) { WL_HIP(hipStreamSynchronize(ctx().stream)); return 0; }
-int wl_malloc(void **p, size_t bytes) { WL_HIP(hipMalloc(p, bytes)); return 0; }
+int wl_malloc(void **p, size_t bytes) { WL_HIP(wl_dev_alloc(p, bytes)); return 0; }
 int wl_free(void *p) { WL_HIP(hipFree(p)); return 0; }
 int wl_h2d(void *dst, const void *src, size_t bytes) {
     WL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
@@ -963,10 +1005,9 @@ int wl_max(wl_dtype t, const wl_grid *g, const void *a, double *out) {
     WL_RED((red_max<T, DD>(gg, (const T *)a, S)));
 }
 
-int wl_conv_diff(wl_dtype t, const wl_grid *g, void *r, const void *u, double nu, int perdir_mask) {
+int wl_conv_diff(wl_dtype t, const wl_grid *g, void *r, const void *u, void *Phi, double nu, int perdir_mask) {
     WL_GS();
-    WL_DISPATCH(t, g->D, (op_conv_diff<T, DD, false>(gg, (T *)r, (const T *)u, nu, perdir_mask, nullptr, nullptr, 0.0,
-                                                      nullptr, false)));
+    WL_DISPATCH(t, g->D, (conv_diff_phi<T, DD>(gg, (T *)r, (const T *)u, (T *)Phi, nu, perdir_mask)));
 }
 int wl_accelerate(wl_dtype t, const wl_grid *g, void *r, const double acc[3]) {
     WL_GS();
@@ -1064,7 +1105,7 @@ int wl_mg_update_changed(wl_mg *m, wl_flow *a) {
     a->changed_pending = false;   // consumed (by the partial or by the full update below)
     if (!usable) return wl_mg_update(m);
     const long nrows = (long)gm.n[1] * gm.n[2];
-    if (!m->dirty) WL_HIP(hipMalloc((void **)&m->dirty, (size_t)nrows));
+    if (!m->dirty) WL_HIP(wl_dev_alloc((void **)&m->dirty, (size_t)nrows));
     // D, iD and the row constants of row (j,k) read L of the rows (j,k), (j+1,k), (j,k+1)
     hipLaunchKernelGGL(k_rows_dirty, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, ctx().stream, (const unsigned char *)a->changed,
                        m->dirty, gm.n[1], gm.n[2], (int)yper, (int)zper);
@@ -1090,7 +1131,7 @@ int wl_mg_jacobi(wl_mg *m, int level, int it) {
 }
 int wl_mg_pcg(wl_mg *m, int level, int it, int *n_updates) {
     WL_LEVEL_OK();
-    int rc = [&]() -> int { WL_MG_DISPATCH((op_pcg<T, DD>(lvl<T>(m, level), it, m->permask, m->sc.partials, m->sc.st))); }();
+    int rc = [&]() -> int { WL_MG_DISPATCH((op_pcg<T, DD>(lvl<T>(m, level), it, m->permask, m->sc.partials, m->sc.st, false, -1, level == 0))); }();
     if (rc) return rc;
     if (n_updates) {
         WL_TRY(m->sc.fetch());
@@ -1167,7 +1208,7 @@ int wl_flow_create(wl_flow **out, wl_dtype t, const wl_flow_desc *d) {
     int rc = a->sc.init();
     if (rc) { delete a; return rc; }
     const size_t nrows = (size_t)d->g.n[1] * (size_t)(d->g.D > 2 ? d->g.n[2] : 1);
-    if (hipMalloc((void **)&a->rowbuf, nrows) != hipSuccess) { a->sc.release(); delete a; return fail(WL_E_STATE, "hipMalloc(row flags)", __FILE__, __LINE__); }
+    if (wl_dev_alloc((void **)&a->rowbuf, nrows) != hipSuccess) { a->sc.release(); delete a; return fail(WL_E_STATE, "wl_dev_alloc(row flags)", __FILE__, __LINE__); }
     *out = a;
     return 0;
 }
@@ -1346,6 +1387,12 @@ int wl_prof_reset_comm(void) {
 int wl_prof_comm(int64_t out[6]) {
     if (!out) return fail(WL_E_ARG, "wl_prof_comm: null output", __FILE__, __LINE__);
     for (int q = 0; q < 6; ++q) out[q] = ctx().comm ? ctx().comm->cnt[q] : 0;
+    return 0;
+}
+int wl_prof_allocs(int64_t *count, int64_t *bytes) {
+    if (!count || !bytes) return fail(WL_E_ARG, "wl_prof_allocs: null output", __FILE__, __LINE__);
+    *count = ctx().n_alloc;
+    *bytes = ctx().alloc_bytes;
     return 0;
 }
 int wl_prof_counts(int kclass, int64_t *launches, int64_t *cells) {

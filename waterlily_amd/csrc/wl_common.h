@@ -87,8 +87,12 @@ struct Ctx {
     hipEvent_t ev_prod = nullptr, ev_halo = nullptr;
     bool halo_pending = false;
     int64_t n_overlapped = 0;          // stencil launches split around an exchange (wl_prof_overlapped)
+    int64_t n_alloc = 0, alloc_bytes = 0;   // device + pinned-host allocations the library has made (wl_prof_allocs)
 };
 Ctx &ctx();
+// every allocation of the library goes through these two (counted: a steady time step must not allocate, test/alloctest.jl)
+inline hipError_t wl_dev_alloc(void **p, size_t n) { ctx().n_alloc += 1; ctx().alloc_bytes += (int64_t)n; return hipMalloc(p, n); }
+inline hipError_t wl_host_alloc(void **p, size_t n, unsigned flags) { ctx().n_alloc += 1; ctx().alloc_bytes += (int64_t)n; return hipHostMalloc(p, n, flags); }
 int fail(int code, const char *what, const char *file, int line);
 
 #define WL_HIP(expr)                                                        \
@@ -463,6 +467,102 @@ inline int launch_range_red(int kclass, const Range &R, F f, double *partials, i
     hipLaunchKernelGGL((k_range_red<NV, F>), dim3(nb), dim3(WL_BX * WL_BY), 0, ctx().stream, t, f, partials, op, init);
     return (int)hipGetLastError();
 }
+// ---- the ghost SHELL of an array: the cells with at least one index 0 or n-1.  The reference reduces whole arrays
+// (maximum(a.σ), Flow.jl:174; z⋅ϵ, Poisson.jl:131), and two of them carry non-zero ghost values (σ keeps conv_diff!'s flux
+// scratch in its top ghost cells, ϵ its periodic copies), so those reductions visit the shell too -- surface work.
+// Plane p = 2*d + side (side 0: index 0, side 1: index n_d-1) covers, exactly once over all planes, the cells with
+// idx[d] on that side, idx[e] in 1..n_e-2 for e < d and idx[e] anywhere for e > d.  z-slab runs: a rank visits the planes
+// it owns; the two z ghost planes belong to the first / last rank (a periodic ring: only the top one, which the last
+// rank holds as its upper halo plane -- the bottom one is never written by anybody and holds zeros in the reference).
+struct Shell {
+    G g;
+    int kmin, kmax;      // local plane range of the x / y planes
+    int zbot, ztop;      // local index of the global z ghost planes 0 / nzg-1 when this rank visits them, else -1
+    int plane[6];        // the planes of this launch (2*d + side)
+    int np;
+};
+inline Shell mk_shell(const G &g, int planemask) {
+    Shell s;
+    s.g = g;
+    if (g.D < 3) { s.kmin = s.kmax = 0; s.zbot = s.ztop = -1; }
+    else {
+        s.zbot = (!g.zring && g.kg(g.zlo) == 0) ? g.zlo : -1;
+        s.ztop = (g.kg(g.zhi) == g.nzg - 1) ? g.zhi : ((g.zring && g.kg(g.zhi) == g.nzg - 2 && g.zhi + 1 <= g.n[2] - 1) ? g.zhi + 1 : -1);
+        s.kmin = g.zlo;
+        s.kmax = s.ztop >= 0 ? s.ztop : g.zhi;
+    }
+    s.np = 0;
+    for (int p = 0; p < 2 * g.D; ++p) {
+        if (!((planemask >> p) & 1)) continue;
+        if (p == 4 && s.zbot < 0) continue;
+        if (p == 5 && s.ztop < 0) continue;
+        s.plane[s.np++] = p;
+    }
+    for (int q = s.np; q < 6; ++q) s.plane[q] = 0;
+    return s;
+}
+// the cells of plane blockIdx.y, first remaining axis fastest (y / z planes: consecutive lanes = consecutive x)
+#define WL_SHELL_LOOP(s, BODY)                                                                              \
+    {                                                                                                        \
+        const int p__ = s.plane[blockIdx.y], d__ = p__ >> 1, side__ = p__ & 1;                               \
+        const int e1__ = d__ == 0 ? 1 : 0, e2__ = d__ == 2 ? 1 : 2;                                          \
+        int lo__[3], hi__[3];                                                                                \
+        for (int e = 0; e < 3; ++e) {                                                                        \
+            if (e >= s.g.D) { lo__[e] = hi__[e] = 0; }                                                       \
+            else if (e == 2) { lo__[e] = s.kmin; hi__[e] = s.kmax; }                                         \
+            else if (e < d__) { lo__[e] = 1; hi__[e] = s.g.n[e] - 2; }                                       \
+            else { lo__[e] = 0; hi__[e] = s.g.n[e] - 1; }                                                    \
+        }                                                                                                    \
+        if (d__ == 2) lo__[2] = hi__[2] = side__ ? s.ztop : s.zbot;                                          \
+        else lo__[d__] = hi__[d__] = side__ ? s.g.n[d__] - 1 : 0;                                            \
+        const long ext1__ = hi__[e1__] - lo__[e1__] + 1, ext2__ = (s.g.D > 2 || d__ == 2) ? hi__[e2__] - lo__[e2__] + 1 : 1; \
+        for (long pos__ = (long)blockIdx.x * 256 + threadIdx.x; pos__ < ext1__ * ext2__; pos__ += (long)gridDim.x * 256) { \
+            const long q2__ = pos__ / ext1__, q1__ = pos__ - q2__ * ext1__;                                  \
+            int idx[3] = {lo__[0], lo__[1], lo__[2]};                                                        \
+            idx[e1__] = lo__[e1__] + (int)q1__;                                                              \
+            if (s.g.D > 2) idx[e2__] = lo__[e2__] + (int)q2__;                                               \
+            BODY                                                                                             \
+        }                                                                                                    \
+    }
+template <class F> __global__ __launch_bounds__(256) void k_shell(Shell s, F f) { WL_SHELL_LOOP(s, f(idx[0], idx[1], idx[2]);) }
+template <class F> __global__ __launch_bounds__(256) void k_shell_red(Shell s, F f, double *partials, int op, double init) {
+    double acc[1] = {init};
+    WL_SHELL_LOOP(s, f(idx[0], idx[1], idx[2], acc);)
+    block_red<1>(acc, op);
+    if (threadIdx.x == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = acc[0];
+}
+inline int shell_blocks(const G &g, int cap) {
+    long big = 1;
+    for (int d = 0; d < g.D; ++d) {
+        long c = 1;
+        for (int e = 0; e < g.D; ++e) if (e != d) c *= (long)g.n[e];
+        big = c > big ? c : big;
+    }
+    long nb = (big + 255) / 256;
+    if (nb > cap) nb = cap;
+    return (int)(nb < 1 ? 1 : nb);
+}
+// f(i, j, k) over the chosen planes of the shell (k local)
+template <class F> inline int launch_shell(int kclass, const G &g, int planemask, F f) {
+    const Shell s = mk_shell(g, planemask);
+    if (s.np == 0) return 0;
+    Prof p(kclass, 0);
+    hipLaunchKernelGGL((k_shell<F>), dim3(shell_blocks(g, 256), s.np), dim3(256), 0, ctx().stream, s, f);
+    return (int)hipGetLastError();
+}
+// f(i, j, k, acc) reduced over the chosen planes: *np partials (<= 6 * cap) are written from partials[0] on
+template <class F> inline int launch_shell_red(int kclass, const G &g, int planemask, F f, double *partials, int op, double init, int *np,
+                                               int cap = 256) {
+    const Shell s = mk_shell(g, planemask);
+    *np = 0;
+    if (s.np == 0) return 0;
+    const int nb = shell_blocks(g, cap);
+    *np = nb * s.np;
+    Prof p(kclass, 0);
+    hipLaunchKernelGGL((k_shell_red<F>), dim3(nb, s.np), dim3(256), 0, ctx().stream, s, f, partials, op, init);
+    return (int)hipGetLastError();
+}
+
 // `dist`: the reduced quantity lives on a z-slab decomposition -> all-reduce over the ranks before `fin`.
 // `red`: device scratch of >= NV doubles.  fin(const double *vals) runs in one device thread.
 template <int NV, class FIN>

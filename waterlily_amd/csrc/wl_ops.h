@@ -203,12 +203,14 @@ int op_exit_bc(const G &g, T *u, const T *u0, const double *U, double dt_, doubl
     return launch_range(WL_K_BC, R, [=] __device__(int i, int j, int k) { u[gg.at(i, j, k)] -= (T)st->out[0]; });
 }
 
-// generic interior reductions: dot / sum / max / sum of squares (Float64 accumulation, fixed order)
+// generic reductions: dot / sum / max / sum of squares (Float64 accumulation, fixed order)
+// whole: every element of the array, ghost cells included (Base.sum / maximum / LinearAlgebra.dot of the reference); z-slab
+// runs: the planes this rank owns
 template <class T, int D, class F>
-int op_reduce(const G &g, int kclass, int op, double init, F cell, double *partials, State *st, int slot) {
+int op_reduce(const G &g, int kclass, int op, double init, F cell, double *partials, State *st, int slot, bool whole = false) {
     int np = 0;
     const G gg = g;
-    WL_TRY((launch_range_red<1>(kclass, r_inside(g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
+    WL_TRY((launch_range_red<1>(kclass, whole ? r_whole(g) : r_inside(g), [=] __device__(int i, int j, int k, double(&acc)[1]) {
         const double v = cell(gg.at(i, j, k));
         acc[0] = (op == RED_SUM) ? acc[0] + v : (v > acc[0] ? v : acc[0]);
     }, partials, op, init, &np)));
@@ -275,6 +277,50 @@ _Pragma("unroll")
         }
     }
     return rr;
+}
+
+// ---- sigma's ghost cells.  conv_diff!(a.f, a.u, a.σ) uses σ as its flux scratch Φ (Flow.jl:45,59,157,164): the loops over
+// inside_u(N,j) = 3:N_j-1 x 2:N_k (TOP ghost included, util.jl:55-57) and, for a periodic j, over slice(N,2,j,2) leave Φ in
+// σ's top ghost cells, and the reference's whole-array reductions see it there: maximum(a.σ) in CFL (Flow.jl:174), and z⋅ϵ
+// of pcg! on level 1, where z ≡ σ (WaterLily.jl:77) and ϵ's ghosts are periodic copies (Poisson.jl:129,131).  The gather
+// form of conv_diff! has no Φ, so those values are produced here.  A ghost cell I (every index >= 2, at least one == N)
+// ends up with the flux of the LAST (i, j) pair of `for i ∈ 1:n, j ∈ 1:n` whose range contains it: i = n and the largest j
+// with 3 <= I_j <= N_j-1 (I_j == 2 too when j is periodic: lowerBoundary!, Flow.jl:58-59).  A cell that no range contains
+// keeps what it holds (the zero it was created with).  Indices below are 0-based; idx[2] and N[2] are global.
+template <class T, int D>
+__device__ __forceinline__ bool phi_stale(const T *u, long csz, const long (&st)[3], long I, const int (&idx)[3], const int (&N)[3],
+                                          bool zring, int permask, T nu, T &out) {
+    int js = -1;
+    bool plow = false;
+_Pragma("unroll")
+    for (int j = 0; j < D; ++j) {
+        const bool ring = (j == 2) && zring;   // ring of slabs: no z boundary, the halo planes hold the wrapped cells
+        if ((idx[j] >= 2 && idx[j] <= N[j] - 2) || (ring && idx[j] == 1)) { js = j; plow = false; }
+        else if (((permask >> j) & 1) && !ring && idx[j] == 1) { js = j; plow = true; }
+    }
+    if (js < 0) return false;
+    const T *ui = u + (long)(D - 1) * csz, *uj = u + (long)js * csz;
+    const long si = st[D - 1], sj = st[js];
+    const double uf = phi<T>(uj, I, si);
+    const T nud = nu * (T)(ui[I] - ui[I - sj]);
+    out = plow ? (T)(phiuP<T>(ui, I + (long)(N[js] - 4) * sj, I, sj, uf) - (double)nud) : (T)(phiu<T>(ui, I, sj, uf) - (double)nud);
+    return true;
+}
+// write them into sigma (the top planes of the shell; cells with an index 0 are never in a range)
+template <class T, int D>
+int op_sigma_ghosts(const G &g, T *sigma, const T *u, double nu_, int permask) {
+    const G gg = g;
+    const T nu = (T)nu_;
+    const int top = (1 << 1) | (1 << 3) | (D > 2 ? (1 << 5) : 0);
+    return launch_shell(WL_K_CONVDIFF, g, top, [=] __device__(int i, int j, int k) {
+        const int idx[3] = {i, j, D > 2 ? gg.kg(k) : 0};
+        if (i < 1 || j < 1 || (D > 2 && idx[2] < 1)) return;
+        const int N[3] = {gg.n[0], gg.n[1], gg.nzg};
+        const long st[3] = {gg.s[0], gg.s[1], gg.s[2]};
+        const long I = gg.at(i, j, k);
+        T v;
+        if (phi_stale<T, D>(u, gg.sc, st, I, idx, N, gg.zring, permask, nu, v)) sigma[I] = v;
+    });
 }
 
 template <class T, int D, bool FUSE, bool COPY = false>
@@ -847,8 +893,8 @@ _Pragma("unroll")
 }
 
 // CFL  src/Flow.jl:172-182: sigma = flux_out (Float64 via max(0.,.)), dt = min(10, inv(max(sigma)+5nu)).
-// The max runs over inside(sigma): the reference's maximum(a.sigma) also sees ghost cells, which only hold
-// stale flux scratch of conv_diff! (sigma doubles as Phi) -- see DESIGN.md "Deliberate deviations".
+// The max runs over the whole array like the reference's maximum(a.sigma): the interior pass below plus the ghost shell,
+// where sigma holds the flux scratch of the last conv_diff! (sigma doubles as Phi; op_sigma_ghosts).
 // exchange_u (z-slab runs, mom_step!): the end-of-step 2-plane halo exchange of u (it feeds this kernel's u[I+dz] on the last
 // owned plane and the next step's conv_diff!) is issued here on the comm stream; all owned planes but the last are
 // processed while it is in flight.
@@ -908,6 +954,15 @@ _Pragma("unroll")
             }
         }
         if (rcv != 0) WL_TRY((launch_range_red<1>(WL_K_CFL, R, body, partials, RED_MAX, -1e300, &np)));
+    }
+    {   // maximum(a.σ) runs over the WHOLE array (Flow.jl:174): σ's ghost cells hold conv_diff!'s flux scratch (op_sigma_ghosts)
+        int nps = 0;
+        const T *sg = sigma;
+        WL_TRY((launch_shell_red(WL_K_CFL, g, 63, [=] __device__(int i, int j, int k, double(&acc)[1]) {
+            const double v = (double)sg[gg.at(i, j, k)];
+            acc[0] = v > acc[0] ? v : acc[0];
+        }, partials + np, RED_MAX, -1e300, &nps)));
+        np += nps;
     }
     const T nu5 = (T)5 * (T)nu_;
     return launch_finalize<1>(g.dist, partials, np, RED_MAX, -1e300, st->red, [=] __device__(const double *v) {
@@ -1223,7 +1278,8 @@ _Pragma("unroll")
 // points, one array pass less on paper -- was measured slower and removed: see DESIGN.md "measured dead ends".)
 template <class T, int D>
 int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st, bool want_r2 = false,
-           int pre_np = -1) {   // pre_np >= 0: eps = r*iD and the partials of rho are already there (op_prolong_increment_fused)
+           int pre_np = -1,     // pre_np >= 0: eps = r*iD and the partials of rho are already there (op_prolong_increment_fused)
+           bool ghost_z = false) {   // z's ghost cells may hold non-zero values (level 1: z is flow.sigma, see op_sigma_ghosts)
     const LevelT<T> q = p;
     const Range R = r_inside(p.g);
     const T eps10 = (T)10 * Lim<T>::eps;
@@ -1352,6 +1408,21 @@ _Pragma("unroll")
             q.z[I] = v;
             acc[0] += (double)v * (double)q.eps[I];
         }, partials, RED_SUM, 0.0, &np)));
+        if (ghost_z && permask != 0) {
+            // z⋅ϵ is a whole-array dot (Poisson.jl:131).  ϵ's ghost cells are zero except in the planes perBC! fills (:129), and
+            // there z may be non-zero: on level 1 z is flow.σ, whose top ghost cells keep conv_diff!'s flux scratch.  Surface sum
+            // over the periodic planes, appended to the partials of the interior sum.
+            int planes = 0, nps = 0;
+            for (int j = 0; j < D; ++j) if ((permask >> j) & 1) planes |= 3 << (2 * j);
+            const G gg = p.g;
+            double *dst = (rcv == 0 ? PA : partials) + np;
+            WL_TRY((launch_shell_red(WL_K_PCG_MULT, p.g, planes, [=] __device__(int i, int j, int k, double(&acc)[1]) {
+                const long I = gg.at(i, j, k);
+                acc[0] += (double)q.z[I] * (double)q.eps[I];
+            }, dst, RED_SUM, 0.0, &nps, infin ? 32 : 256)));
+            np += nps;
+            if (rcv == 0) npA = np;
+        }
         if (!infin)
         WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
             st->xpend = 0;   // any owed x update was applied by the direction kernel before this mult

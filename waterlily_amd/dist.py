@@ -189,6 +189,18 @@ def init_host(group=None) -> None:
     init_mailbox(group)
 
 
+def init_loopback(rank: int, size: int) -> None:
+    """ONE process plays rank `rank` of a `size`-way z-slab run (include/wlhip.h: wl_comm_init_loopback): measurement of a rank's
+    own compute and launch time on one GPU (bench.py --comm loopback).  No torch.distributed, no mailbox."""
+    _lib.check(_lib.lib().wl_comm_init_loopback(int(rank), int(size)))
+    _state.update(kind="loopback", rank=int(rank), size=int(size))
+
+
+def kind():
+    """"rccl", "host", "loopback" or None: the communicator this process installed"""
+    return _state["kind"]
+
+
 def init_mailbox(group=None) -> bool:
     """Switch the scalar all-reduces of the run to the library's mailbox (include/wlhip.h: wl_comm_mailbox): rank 0 creates a
     POSIX shared-memory object, every rank of the node maps it.  WL_MAILBOX=0 in the environment keeps ncclAllReduce / the

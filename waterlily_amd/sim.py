@@ -177,7 +177,7 @@ def _same_layout(a: torch.Tensor, b: torch.Tensor) -> None:
 
 
 def dot(a: torch.Tensor, b: torch.Tensor) -> float:
-    """LinearAlgebra.dot over inside(a) (src/Poisson.jl:126-146)"""
+    """LinearAlgebra.dot over the whole arrays, ghost cells included (src/Poisson.jl:126-146)"""
     _same_layout(a, b)
     out = C.c_double()
     g = _grid_of(a, a.ndim)
@@ -377,10 +377,14 @@ def time(a: Flow) -> float:
 
 
 def conv_diff(r: torch.Tensor, u: torch.Tensor, Phi=None, nu=0.1, perdir=()):
-    """Flow.jl:36-51 (Phi is accepted for signature parity; the gather kernel needs no scratch)."""
+    """Flow.jl:36-51.  The gather kernels need no scratch; when Phi is given its top ghost cells receive what the reference's
+    scatter form leaves there (include/wlhip.h: wl_conv_diff)."""
     _same_layout(r, u)
     g = _grid_of(u, u.ndim - 1)
-    check(_lib.lib().wl_conv_diff(_WLT[_T(u)], C.byref(g), _ptr(r), _ptr(u), float(nu), permask(perdir)))
+    if Phi is not None and (tuple(Phi.shape) != tuple(u.shape[:-1]) or Phi.stride() != u.stride()[:-1]):
+        raise ValueError("Phi and u must share the grid layout")
+    check(_lib.lib().wl_conv_diff(_WLT[_T(u)], C.byref(g), _ptr(r), _ptr(u), None if Phi is None else _ptr(Phi), float(nu),
+                                  permask(perdir)))
 
 
 def accelerate(r: torch.Tensor, acc) -> None:
