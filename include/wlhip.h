@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 5
+#define WL_ABI_VERSION 6
 
 typedef enum wl_dtype { WL_F32 = 0, WL_F64 = 1 } wl_dtype;
 
@@ -92,8 +92,9 @@ int wl_comm_init_loopback(int rank, int nranks);
  * have returned before the others call (the host orders it: create on rank 0, barrier, open elsewhere, barrier, then rank 0
  * may shm_unlink the name).  From then on the library sums its scalars through that block of pinned host memory -- one
  * system-scope store + one poll per peer, combined in rank order (bit-identical on every rank) -- instead of one RCCL
- * all-reduce per value; halo planes and the coarse-level all-gather stay on RCCL.  Waits are bounded: a rank that gives up
- * reports WL_E_STATE at the caller's next synchronising call.  Optional: without it scalars use ncclAllReduce. */
+ * all-reduce per value; halo planes and the coarse-level all-gather stay on RCCL.  Waits are bounded in wall-clock time
+ * (wl_set_option(26), seconds; 0 = unbounded): a rank that gives up reports WL_E_STATE at the caller's next synchronising
+ * call.  Optional: without it scalars use ncclAllReduce. */
 int wl_comm_mailbox(const char *shm_name, int create);
 int wl_comm_mailbox_off(void);          /* back to the communicator's all-reduce (every rank must call it at the same point) */
 int wl_comm_mailbox_active(int *on);
@@ -293,16 +294,28 @@ enum { WL_M_KE = 0, WL_M_CURL = 1, WL_M_OMAG = 2, WL_M_OTHETA = 3, WL_M_LAMBDA2 
 int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, int ipar, const double par[3],
               const double par2[3]);
 
-/* ------------------------------------------------------------------ tuning switches (A/B measurements)
+/* ------------------------------------------------------------------ snapshots (VTK write / restart, ext/WaterLilyWriteVTKExt.jl:57-66,
+ * ext/WaterLilyReadVTKExt.jl:28-45).  The reference copies whole fields to the host (`a.flow.u |> Array`) and permutes the vector
+ * components to the front there (components_first, :79).  Here the field's LOCAL planes klo..khi are packed on the device into
+ * a dense array-of-tuples staging buffer -- dst[((kk*n1 + j)*n0 + i)*ntuple + c] = a_c[i, j, klo+kk] for c < ncomp, 0 for the
+ * padding components ncomp <= c < ntuple (VTK vectors carry 3) -- which the host then moves with ONE asynchronous copy on a
+ * side stream while the next time step runs; unpack is the inverse (restart).  Enqueued on the library's stream. */
+int wl_snapshot_pack(wl_dtype t, const wl_grid *g, const void *a, int ncomp, int ntuple, int klo, int khi, void *dst);
+int wl_snapshot_unpack(wl_dtype t, const wl_grid *g, void *a, int ncomp, int ntuple, int klo, int khi, const void *src);
+
+/* ------------------------------------------------------------------ switches
+ * Every key selects between the form of an operator the reference writes and a traffic-saving form of it that produces the
+ * same bits (tests flip them one by one, and all at once); a few are tuning values.  The defaults are the measured winners;
+ * round 4 retired the keys whose alternative was a recorded loss (11, 12, 20, 21, 24, 25, 28: DESIGN.md, measured dead ends).
  * key 0: 1 = use the 16-B-vectorised z-marching 7-point kernel where it applies (default), 0 = generic range kernel
  * key 1: 1 = fused V-cycle smoothers (default), 0 = the reference's two-pass Jacobi!/increment!/prolongate!
  * key 2: 1 = LDS-tiled marching conv_diff kernel (default), 0 = generic gather kernel
  * key 3: 1 = BDIM! uses the body-free row flags (default), 0 = general path everywhere
+ * key 4: rows per thread of the vectorised 7-point kernel (a 256-thread workgroup covers 4x that many rows): 1, 2, or
+ *        0 (default) = 2 on levels of >= 2^26 interior cells with an even y extent, else 1.  Same values either way.
  * key 5: != 0 = 16-B vectorised streaming pcg kernels (default), 0 = scalar range kernels
  * key 6: 1 = multigrid levels <= 4096 cells run as one single-workgroup launch per V-cycle (default), 0 = per-op launches
  * key 7: 1 = BC! as one closed-form launch (default), 0 = the reference's sequence of plane loops
- * key 4: rows per thread of the vectorised 7-point kernel (a 256-thread workgroup covers 4x that many rows): 1, 2, or
- *        0 (default) = 2 on levels of >= 2^26 interior cells with an even y extent, else 1.  Same values either way.
  * key 8: 1 = pcg! applies x += alpha*eps in the direction kernel instead of the update kernel (default; one array
  *        pass less per iteration, identical values), 0 = in the update kernel as the reference orders it
  * key 9: 1 = the 7-point kernels skip the loads of L in rows whose face coefficients are all one number (rows clear
@@ -310,37 +323,33 @@ int wl_metric(wl_dtype t, const wl_grid *g, int kind, void *out, const void *u, 
  * key 10: 1 = inside solver! the start of pcg! (eps = r*iD, rho) is evaluated by the prolongate!+increment! kernel that
  *         has just produced r (default), 0 = by pcg!'s own first kernel
  * key 13: 1 = pcg! does not store z' = r*iD, the direction kernel recomputes it (default), 0 = stored as in the reference
+ * key 14: 1 = inside mom_step! the predictor's closing `x ./= dt` and the corrector's opening `x .*= 0.5dt`
+ *         (Flow.jl:144,139) are one pass over x, each rounding kept (default), 0 = two passes
  * key 15: 1 = on levels of at most 2^25 cells pcg!'s dot products are finished by the kernel that follows (no
  *         one-workgroup finalize launches inside a pcg! call; single rank) (default), 2 = on every level, 0 = separate
  *         finalize launch after every dot product
- * key 14: 1 = inside mom_step! the predictor's closing `x ./= dt` and the corrector's opening `x .*= 0.5dt`
- *         (Flow.jl:144,139) are one pass over x, each rounding kept (default), 0 = two passes
+ * keys 16, 17: grid size of the 7-point / streaming vector kernels in units of 1024 workgroups (defaults 4 / 16: measured
+ *         at 512^3, the streaming kernels gain 3-6 % from shorter z-chunks, the 7-point kernels do not)
  * key 18: 1 = conv_diff! evaluates each interior face flux once and shares it between the two cells (shared-flux LDS kernel
- *         on the tiles / planes whose y and z faces are all interior) (default), 0 = every cell gathers its six fluxes
+ *         on the tiles / planes whose y and z faces are all interior; 64x8 tiles in Float32, 64x4 in Float64) (default),
+ *         0 = every cell gathers its six fluxes
  * key 19: 1 = on levels of 2^22 .. 2^26 cells pcg! does not store z = A*eps: its update kernel is a second 7-point kernel over
  *         eps that forms the same A*eps again and applies r -= alpha*(A*eps) (default; 3-D vector kernels), 3 = on every
  *         level below 2^26 cells, 2 = on every level, 0 = the mult kernel always stores z
- * key 20: 1 = the shared-flux conv_diff! kernel uses 64x8 tiles (512-thread workgroups) for Float32 (default), 0 = 64x4
  * key 22: 1 = inside wl_mom_step / wl_project (3-D, one device) z = div(u) is formed by the residual! kernel itself, the
  *         z array is neither written nor read (default), 0 = separate div pass
  * key 23: 1 = inside wl_mom_step (3-D, x not periodic) the x-ghost cells of the interior rows that BC!(u,U) sets are
  *         written by the kernel that has just produced the row (BDIM!, the velocity correction); the BC launch that
  *         follows covers the y and z planes only (default), 0 = BC! writes all six planes
- * key 21: 1 = the two x-ghost planes of a 3-D conv_diff! are one launch that stages its operands in LDS (default),
- *         0 = two launches of the per-cell gather
- * keys 16, 17: grid size of the 7-point / streaming vector kernels in units of 1024 workgroups (defaults 4 / 16: measured
- *         at 512^3, the streaming kernels gain 3-6 % from shorter z-chunks, the 7-point kernels do not)
+ * key 26: bound of a mailbox all-reduce's wait for a peer in SECONDS of the device's wall clock (default 600; 0 = unbounded,
+ *         like a collective)
  * key 30: 1 = consecutive marching kernels sweep their tiles in opposite directions, each XCD starting on the lines the
  *         kernel before it touched last (L2 / Infinity Cache) (default), 0 = always ascending.  Same bits either way.
  * key 31: 1 = inside the one-workgroup bottom of the V-cycle (levels of <= 4096 cells) pcg! keeps its level in registers and
  *         LDS for the whole call (default), 0 = every phase goes through global memory.  Same bits either way.
- * key 28: grid size of the velocity-correction kernel in units of 1024 workgroups (default 16; 4: 5 % slower at 512^3)
- * key 26: bound of a mailbox all-reduce's wait for a peer, in thousands of polls (default 40000, about a minute)
- * key 25: 1 = the shared-flux conv_diff! kernel uses 64x8 tiles for Float64 too (86.6 KB of LDS per workgroup), 0 = 64x4 (default)
- * key 24: budget of per-workgroup partials a pcg! kernel may sum itself (key 15): the grid of the kernels of such a call is
- *         capped at this many workgroups (default 1024, at most 16384)
- * keys 11, 12: > 0 = cap on the number of z-chunks of the 7-point / streaming vector kernels (measurement only) */
+ * Any other key: WL_E_ARG. */
 int wl_set_option(int key, int value);
+int wl_get_option(int key, int *value);
 
 /* ------------------------------------------------------------------ measurement support */
 /* Kernel classes for launch counting and HIP-event timing (bench.py roofline leg). */

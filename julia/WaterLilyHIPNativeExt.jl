@@ -1,4 +1,4 @@
-# WaterLilyHIPNativeExt.jl -- reference-side binding of libwlhip.so (include/wlhip.h, ABI v5).
+# WaterLilyHIPNativeExt.jl -- reference-side binding of libwlhip.so (include/wlhip.h, ABI v6).
 #
 # NOT EXECUTED by this repository's tests: no Julia runtime exists in the build image or on the GPU box.  It is the
 # shim a WaterLily maintainer would add as a package extension (compare ext/WaterLilyAMDGPUExt.jl): a device array type

@@ -273,11 +273,13 @@ def test_rccl_two_devices(case):
 
 @pytest.mark.gpu
 def test_bench_multirank_path():
-    """bench.py's N>1 code path (slab set-up, timing reduction, JSON line) with 2 ranks sharing the GPU over gloo."""
+    """bench.py's N>1 code path under the driver's launcher (slab set-up, timing reduction, JSON line) with 2 ranks sharing the GPU
+    over gloo, in its weak-scaling form (--weak: every rank keeps a size^3 slab; the default is strong scaling, covered by
+    tests/test_boundary_hosts.py::test_bench_launches_its_own_ranks)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "host", "--size", "64",
-           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+           "--weak", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

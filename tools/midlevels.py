@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time of ONE pcg!(it=6) call on a level of n^3 cells (the multigrid levels below the finest one), as the finest level of
 its own small hierarchy: mean over `reps` calls, r restored before each call (the copy is timed separately and
-subtracted).  usage: midlevels.py [--f64] [key=v1,v2,...]   e.g.  midlevels.py 24=256,512,1024,2048"""
+subtracted).  usage: midlevels.py [--f64] [key=v1,v2,...]   e.g.  midlevels.py 15=0,1   (key 24, the partial budget swept in round 3, is a constant now)"""
 import ctypes as C
 import os
 import sys
@@ -16,7 +16,7 @@ from waterlily_amd import sim as S  # noqa: E402
 
 T = np.float64 if "--f64" in sys.argv else np.float32
 sweep = [a for a in sys.argv[1:] if "=" in a]
-key, vals = (int(sweep[0].split("=")[0]), [int(v) for v in sweep[0].split("=")[1].split(",")]) if sweep else (24, [1024])
+key, vals = (int(sweep[0].split("=")[0]), [int(v) for v in sweep[0].split("=")[1].split(",")]) if sweep else (15, [1])
 L = _lib.lib()
 reps = 50
 
@@ -60,4 +60,4 @@ for n in (256, 128, 64, 32):
         _lib.check(L.wl_mg_pcg(ml._h, 0, 6, C.byref(nu)))
     print(f"  {n:4d}^3: " + "  ".join(f"[{v}] {t:8.1f}" for v, t in zip(vals, row)) + f"   (copy {tcopy:.1f} us, updates of the last call {nu.value})")
     del a, ml
-S.set_option(key, 1024 if key == 24 else 1)
+S.set_option(key, 1)

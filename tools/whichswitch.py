@@ -16,7 +16,7 @@ from waterlily_amd import sim as S  # noqa: E402
 n = int(sys.argv[1])
 T = np.float64 if "--f64" in sys.argv else np.float32
 mk = bench.donut if "--donut" in sys.argv else bench.sphere
-KEYS = (3, 8, 9, 13, 14, 18, 19, 20, 21, 22, 23, 30)
+KEYS = (3, 8, 9, 13, 14, 18, 19, 22, 23, 30)
 
 
 def run(off=()):

@@ -150,7 +150,10 @@ def lib() -> C.CDLL:
         "wl_pforce": (i, [i, gp, vp, vp, vp, i64, dp]),
         "wl_vforce": (i, [i, gp, vp, vp, vp, i64, d, dp]),
         "wl_pmoment": (i, [i, gp, vp, vp, vp, i64, dp, dp]),
+        "wl_snapshot_pack": (i, [i, gp, vp, i, i, i, i, vp]),
+        "wl_snapshot_unpack": (i, [i, gp, vp, i, i, i, i, vp]),
         "wl_set_option": (i, [i, i]),
+        "wl_get_option": (i, [i, ip]),
         "wl_kernel_name": (C.c_char_p, [i]),
         "wl_prof_select": (i, [i, i64]),
         "wl_prof_reset": (i, []),
@@ -166,7 +169,7 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.wl_abi_version() != 5:
+    if L.wl_abi_version() != 6:
         raise WlError("libwlhip.so ABI version mismatch; rebuild it")
     _lib = L
     return L

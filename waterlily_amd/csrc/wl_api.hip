@@ -771,6 +771,28 @@ template <class KERNEL> static int band_reduce(const G &gg, Scratch &S, int64_t 
     for (int c = 0; c < D; ++c) out[c] = S.hst->out[c];
     return 0;
 }
+// Snapshot staging (VTK write / restart): planes klo..khi of a field <-> a DENSE array-of-tuples buffer on the device,
+// dst[((kk*n1 + j)*n0 + i)*nct + c] = a_c[i, j, klo+kk] (c < ncomp; 0 for ncomp <= c < nct): the row padding goes, the components
+// interleave (VTK's tuple order, ext/WaterLilyWriteVTKExt.jl:79 components_first).  One wavefront per x-row.
+template <class T, bool PACK>
+__global__ __launch_bounds__(256) void k_snapshot(G g, T *a, int ncomp, int nct, int klo, long nrows, T *buf) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int j = (int)(row % g.n[1]), kk = (int)(row / g.n[1]);
+    const long src = g.at(0, j, klo + kk), dst = row * (long)g.n[0];
+    for (int i = threadIdx.x & 63; i < g.n[0]; i += 64)
+        for (int c = 0; c < nct; ++c) {
+            if (PACK) buf[(dst + i) * nct + c] = c < ncomp ? a[(long)c * g.sc + src + i] : (T)0;
+            else if (c < ncomp) a[(long)c * g.sc + src + i] = buf[(dst + i) * nct + c];
+        }
+}
+template <class T> static int snapshot_copy(const G &g, T *a, int ncomp, int nct, int klo, int khi, T *buf, bool pack) {
+    const long nrows = (long)g.n[1] * (khi - klo + 1);
+    Prof p(WL_K_COPY, nrows * g.n[0] * nct);
+    if (pack) hipLaunchKernelGGL((k_snapshot<T, true>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ctx().stream, g, a, ncomp, nct, klo, nrows, buf);
+    else hipLaunchKernelGGL((k_snapshot<T, false>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ctx().stream, g, a, ncomp, nct, klo, nrows, buf);
+    return (int)hipGetLastError();
+}
 template <class T, int D> static int restrictL_full(const G &A, T *a, const G &B, const T *b, int permask) {
     WL_TRY((op_restrictL<T, D>(A, a, B, b, permask)));
     return coarse_L_finish<T, D>(A, a, B, permask);
@@ -867,6 +889,12 @@ int wl_comm_mailbox(const char *shm_name, int create) {
         return fail((int)e, "wl_comm_mailbox: device mapping", __FILE__, __LINE__);
     }
     mb->dev = (MboxSlot *)dp;
+    if (ctx().wall_khz <= 0.0) {   // ticks per millisecond of wall_clock64() (constant-rate counter: 100 MHz on gfx9)
+        int dev = 0, khz = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0)
+            ctx().wall_khz = (double)khz;
+        else ctx().wall_khz = 1e5;
+    }
     ctx().mbox = mb;
     return 0;
 }
@@ -1328,9 +1356,35 @@ int wl_pforce(wl_dtype t, const wl_grid *g, const void *p, const int64_t *idx, c
     return 0;
 }
 
+static int snapshot_args(const wl_grid *g, const void *a, int ncomp, int nct, int klo, int khi, const void *buf) {
+    WL_TRY(check_grid(g));
+    if (!a || !buf) return fail(WL_E_ARG, "wl_snapshot: null buffer", __FILE__, __LINE__);
+    if (ncomp < 1 || nct < ncomp || nct > 9) return fail(WL_E_ARG, "wl_snapshot: need 1 <= ncomp <= ntuple <= 9", __FILE__, __LINE__);
+    const int n2 = g->D == 3 ? g->n[2] : 1;
+    if (klo < 0 || khi >= n2 || klo > khi) return fail(WL_E_ARG, "wl_snapshot: plane range outside the local array", __FILE__, __LINE__);
+    return 0;
+}
+int wl_snapshot_pack(wl_dtype t, const wl_grid *g, const void *a, int ncomp, int ntuple, int klo, int khi, void *dst) {
+    WL_TRY(snapshot_args(g, a, ncomp, ntuple, klo, khi, dst));
+    const G gg = mkG(g);
+    if (t == WL_F32) return snapshot_copy<float>(gg, (float *)const_cast<void *>(a), ncomp, ntuple, klo, khi, (float *)dst, true);
+    return snapshot_copy<double>(gg, (double *)const_cast<void *>(a), ncomp, ntuple, klo, khi, (double *)dst, true);
+}
+int wl_snapshot_unpack(wl_dtype t, const wl_grid *g, void *a, int ncomp, int ntuple, int klo, int khi, const void *src) {
+    WL_TRY(snapshot_args(g, a, ncomp, ntuple, klo, khi, src));
+    const G gg = mkG(g);
+    if (t == WL_F32) return snapshot_copy<float>(gg, (float *)a, ncomp, ntuple, klo, khi, (float *)const_cast<void *>(src), false);
+    return snapshot_copy<double>(gg, (double *)a, ncomp, ntuple, klo, khi, (double *)const_cast<void *>(src), false);
+}
+
 int wl_set_option(int key, int value) {
-    if (key < 0 || key >= 32) return fail(WL_E_ARG, "wl_set_option: bad key", __FILE__, __LINE__);
+    if (key < 0 || key >= 32 || !((WL_OPT_LIVE >> key) & 1u)) return fail(WL_E_ARG, "wl_set_option: no such option", __FILE__, __LINE__);
     ctx().opt[key] = value;
+    return 0;
+}
+int wl_get_option(int key, int *value) {
+    if (!value || key < 0 || key >= 32 || !((WL_OPT_LIVE >> key) & 1u)) return fail(WL_E_ARG, "wl_get_option: no such option", __FILE__, __LINE__);
+    *value = ctx().opt[key];
     return 0;
 }
 

@@ -70,7 +70,9 @@ struct Mailbox {
 
 struct Ctx {
     Mailbox *mbox = nullptr;
-    int opt[32] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 1, 1, 1, 1, 1024, 0, 40000, 0, 16, 0, 1, 1};   // wl_set_option
+    // wl_set_option (include/wlhip.h); keys 11, 12, 20, 21, 24, 25, 27, 28, 29 are retired (WL_OPT_LIVE)
+    int opt[32] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 0, 0, 1, 1, 0, 0, 600, 0, 0, 0, 1, 1};
+    double wall_khz = 0.0;             // rate of the device's wall clock (mailbox time-outs), read when the mailbox is made
     Comm *comm = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -93,6 +95,8 @@ Ctx &ctx();
 // every allocation of the library goes through these two (counted: a steady time step must not allocate, test/alloctest.jl)
 inline hipError_t wl_dev_alloc(void **p, size_t n) { ctx().n_alloc += 1; ctx().alloc_bytes += (int64_t)n; return hipMalloc(p, n); }
 inline hipError_t wl_host_alloc(void **p, size_t n, unsigned flags) { ctx().n_alloc += 1; ctx().alloc_bytes += (int64_t)n; return hipHostMalloc(p, n, flags); }
+// live wl_set_option keys: 0-10, 13-19, 22, 23, 26, 30, 31
+constexpr unsigned WL_OPT_LIVE = 0xC4CFE7FFu;
 int fail(int code, const char *what, const char *file, int line);
 
 #define WL_HIP(expr)                                                        \
@@ -372,14 +376,15 @@ template <class FIN> __global__ void k_apply(const double *red, FIN fin) { fin(r
 
 // local reduction (exactly k_reduce_only) + the exchange through the mailbox: red[q] = op over the ranks, in rank order.
 // Slot (seq & 1, rank) is written by its owner only; a rank can be at most one all-reduce ahead of the slowest one (it
-// needs that rank's value of the current round to finish it), so two parities suffice.  Every wait is BOUNDED: after
-// WL_MBOX_SPINS polls a lane gives up, raises the error flag (the host turns it into an error at its next
-// synchronisation) and the values become NaN -- the grid always drains.
-// (bound: wl_set_option(26) thousand polls, default 40 000 000 polls x (one PCIe read + s_sleep) ~ a minute)
+// needs that rank's value of the current round to finish it), so two parities suffice.  A wait is bounded in WALL-CLOCK
+// time (wl_set_option(26) seconds on the device's constant-rate clock, default 600; 0 = wait for ever, like a collective
+// would): a lane that gives up raises the error flag (the host turns it into an error at its next synchronisation) and the
+// values become NaN -- the grid always drains.  Ranks may legitimately be apart by the length of rank-asymmetric host work
+// (a first-call compile, geometry, file output): the default leaves minutes for that.
 constexpr int WL_MBOX_MAXRANKS = 64;
 template <int NV>
 __global__ __launch_bounds__(WL_FIN_T) void k_reduce_mbox(const double *partials, int np, int op, double init, double *red, MboxSlot *mb,
-                                                          int rank, int nranks, unsigned long long seq, int *err, long spin_limit) {
+                                                          int rank, int nranks, unsigned long long seq, int *err, long long tick_limit) {
     double acc[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
@@ -401,10 +406,10 @@ __global__ __launch_bounds__(WL_FIN_T) void k_reduce_mbox(const double *partials
     }
     if ((int)threadIdx.x < nranks) {   // collect: one lane per peer (the own slot included: same path, same order)
         MboxSlot *s = slots + threadIdx.x;
-        long spins = 0;
+        const long long t0 = wall_clock64();
         bool ok = true;
         while (__hip_atomic_load(&s->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            if (++spins > spin_limit) { ok = false; break; }
+            if (tick_limit > 0 && wall_clock64() - t0 > tick_limit) { ok = false; break; }
             __builtin_amdgcn_s_sleep(16);
         }
 #pragma unroll
@@ -431,7 +436,7 @@ template <int NV> inline int reduce_allreduce(const double *partials, int np, in
         cm->cnt[0] += 1;
         mb->seq += 1;
         hipLaunchKernelGGL((k_reduce_mbox<NV>), dim3(1), dim3(WL_FIN_T), 0, ctx().stream, partials, np, op, init, red, mb->dev, cm->rank,
-                           cm->size, mb->seq, mb->err_dev, 1000L * (long)(ctx().opt[26] > 0 ? ctx().opt[26] : 1));
+                           cm->size, mb->seq, mb->err_dev, (long long)((double)(ctx().opt[26] > 0 ? ctx().opt[26] : 0) * ctx().wall_khz * 1e3));
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((k_reduce_only<NV>), dim3(1), dim3(WL_FIN_T), 0, ctx().stream, partials, np, op, init, red);

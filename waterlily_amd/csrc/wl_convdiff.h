@@ -511,9 +511,10 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
     // planes with interior z faces only, clipped to the owned planes
     int klo = g.zlo, khi = g.zhi;
     if (!g.zring) { klo = max(klo, 2 - g.kz0); khi = min(khi, g.nzg - 3 - g.kz0); }
-    // Float64: 8-row tiles need 86.6 KB of LDS = ONE 512-thread workgroup (8 wavefronts) per CU where the 4-row tiles run
-    // three 256-thread workgroups (12 wavefronts); wl_set_option(25, 1) selects them (measured: see DESIGN.md section 5)
-    const bool use8 = (sizeof(T) == 4 && ctx().opt[20] != 0) || (sizeof(T) == 8 && ctx().opt[20] != 0 && ctx().opt[25] != 0);
+    // Float32: 8-row tiles (43 KB of LDS per 512-thread workgroup).  Float64 stays on 4-row tiles: 8 rows would need 86.6 KB =
+    // ONE workgroup of 8 wavefronts per CU where the 4-row tiles run three of 4 -- built and measured slower in round 3
+    // (3.30 -> 3.55 ms per launch at 512^3; DESIGN.md, measured dead ends), removed in round 4
+    const bool use8 = sizeof(T) == 4;
     int thi_s = thi;
     if (use8 && ((thi_s - tlo + 1) & 1) && thi_s > tlo) --thi_s;   // 8-row tiles: an odd tile row goes to the shell
     const bool shared = ctx().opt[18] != 0 && thi_s >= tlo && khi >= klo;
@@ -545,20 +546,13 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
         const int nblk = tpp * nchunk;
         Prof p(WL_K_CONVDIFF, (long)g.n[0] * (long)(ntr * BY) * nown);
         constexpr size_t lds = sizeof(CdsShared<T, BY>);
-        if (lds > 64 * 1024) {
-            static bool raised = false;   // (per instantiation)
-            if (!raised) {
-                WL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_convdiff3s<T, FUSE, COPY, BY>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                raised = true;
-            }
-        }
+        static_assert(lds <= 64 * 1024, "conv_diff tile: more LDS than a launch gets without opting in");
         hipLaunchKernelGGL((k_convdiff3s<T, FUSE, COPY, BY>), dim3(nblk), dim3(CD_BX * BY), lds, ctx().stream, g, r, u, (T)nu_, u0, u0out, V,
                            (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen, jbase, klo, khi, ntile, rev);
         return (int)hipGetLastError();
     };
     const int rows = nty * CD_BY, jb0 = tlo * CD_BY;
-    if (use8) {
+    if constexpr (sizeof(T) == 4) {
         const int n8 = rows / 8;
         WL_TRY(launch(std::integral_constant<int, 8>{}, jb0, n8));
         return launch(std::integral_constant<int, 4>{}, jb0 + 8 * n8, (rows - 8 * n8) / 4);

@@ -451,12 +451,7 @@ int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T 
             }
             // (the two x-ghost planes -- strided, latency-bound, 0.07 + 0.21 ms at 512^3 -- were also tried on a side stream
             //  next to the LDS kernel: no gain, 29.73 vs 29.74 ms per step)
-            if (ctx().opt[21]) return launch_convdiff_xghost<T, FUSE, COPY>(g, r, u, nu_, u0, V, dt_, acc, has_acc, u0out);
-            Range R0 = r_whole(g), R1 = r_whole(g);
-            R0.hi[0] = 0;
-            R1.lo[0] = g.n[0] - 1;
-            WL_TRY((op_conv_diff_range<T, D, FUSE, COPY>(g, R0, r, u, nu_, permask, u0, V, dt_, acc, has_acc, u0out)));
-            return op_conv_diff_range<T, D, FUSE, COPY>(g, R1, r, u, nu_, permask, u0, V, dt_, acc, has_acc, u0out);
+            return launch_convdiff_xghost<T, FUSE, COPY>(g, r, u, nu_, u0, V, dt_, acc, has_acc, u0out);
         }
     }
     if (exchange_u) WL_TRY((halo_exchange<T>(g, const_cast<T *>(u), D, 2)));
@@ -871,7 +866,7 @@ int op_correct(const G &g, T *u, const T *L, const T *x, const T *rowc = nullptr
             const int tpp = ((ntx * nty + 7) / 8) * 8;
             const int nown = R.hi[2] - R.lo[2] + 1;
             int clen, nchunk;
-            chunking(tpp, nown, 0, ctx().opt[28], &clen, &nchunk);   // wl_set_option(28): grid size in units of 1024 workgroups
+            chunking(tpp, nown, 0, 16, &clen, &nchunk);   // 16 K workgroups, like the streaming kernels (4 K: 5 % slower at 512^3)
             Prof p(WL_K_CORRECT, R.count());
             const XBc<T> xb = (xbc && xbc->on) ? *xbc : XBc<T>{0, 0, (T)0};
             hipLaunchKernelGGL((k_correct3<T>), dim3(tpp * nchunk), dim3(64 * S7_BY), 0, ctx().stream, g, u, L, x, rowc, ntx, tpp,
@@ -1210,8 +1205,8 @@ int op_prolong_increment_fused(const LevelT<T> &p, const T *rin, const G &gc, co
             if (pcg_np && partials && ctx().opt[10] && ctx().opt[13] && ctx().opt[5]) {
                 T *e0 = p.eps;
                 const int tpp = (((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 3) / 4) + 7) / 8 * 8;
-                const int keep = ctx().opt[11];
-                if (tpp <= ctx().opt[24]) ctx().opt[11] = ctx().opt[24] / tpp;   // few partials: pcg!'s first mult kernel may sum them itself
+                Gate gcap;
+                if (tpp <= WL_PCG_PARTIALS) gcap.zcap = WL_PCG_PARTIALS / tpp;   // few partials: pcg!'s first mult kernel may sum them itself
                 int np = 0;
                 const int rcv = launch_stencil7<T, 1>(WL_K_PROLONG, p.g, src, p.L, p.rowc, rin, p.x,
                     [=] __device__(long o, int i, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, const auto &rk, double *acc, const Pre &) {
@@ -1225,8 +1220,7 @@ _Pragma("unroll")
 _Pragma("unroll")
                         for (int v = 0; v < VA::V; ++v) { ev.v[v] = rv.v[v] * id.v[v]; acc[0] += (double)rv.v[v] * (double)ev.v[v]; }
                         ev.store(e0 + o);
-                    }, partials, &np);
-                ctx().opt[11] = keep;
+                    }, partials, &np, gcap);
                 if (rcv > 0) return rcv;
                 if (rcv == 0) { *pcg_np = np; return 0; }
             }
@@ -1317,12 +1311,9 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     const bool distr = p.g.dist && ctx().comm && ctx().comm->size > 1;
     const bool infin = vec && xdef && zrec && R.count() > 0 && tpp_v > 0 &&
                        (distr ? ctx().opt[15] != 0
-                              : ((ctx().opt[15] == 2 || (ctx().opt[15] == 1 && R.count() <= (1L << 25))) && tpp_v <= ctx().opt[24]));
-    struct CapGuard {   // the in-kernel sums want few partials: cap the number of z-chunks for the kernels of this call
-        int o11, o12; bool on;
-        CapGuard(bool on_, int cap) : o11(ctx().opt[11]), o12(ctx().opt[12]), on(on_) { if (on) { ctx().opt[11] = cap; ctx().opt[12] = cap; } }
-        ~CapGuard() { if (on) { ctx().opt[11] = o11; ctx().opt[12] = o12; } }
-    } capguard(infin && !distr, (infin && !distr) ? std::max(ctx().opt[24] / std::max(tpp_v, 1), 1) : 0);
+                              : ((ctx().opt[15] == 2 || (ctx().opt[15] == 1 && R.count() <= (1L << 25))) && tpp_v <= WL_PCG_PARTIALS));
+    // the in-kernel sums want few partials: the kernels of such a call cut z into at most `zcap` chunks (Gate::zcap)
+    const int zcap = (infin && !distr) ? std::max(WL_PCG_PARTIALS / std::max(tpp_v, 1), 1) : 0;
     // what the consuming gate sums: the producer's partials, or (z-slabs) the one all-reduced value
     auto ready = [&](const double *&part, int &n) -> int {
         if (!distr) return 0;
@@ -1340,6 +1331,8 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     int rv0 = -1;
     if (pre_np >= 0) { rv0 = 0; np = np0 = pre_np; }
     else if (vec) {
+        Gate gate_init;
+        gate_init.zcap = zcap;
         rv0 = launch_rowvec<T, 1, true>(WL_K_PCG_INIT, p.g,
             [=] __device__(long o, int, int, const Pre &) { return VA::load(q.r + o); },
             [=] __device__(long o, int i, int, int, const VA &rr, const auto &rk, double *acc, const Pre &) {
@@ -1349,7 +1342,7 @@ _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) { zv.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zv.v[v]; }
                 if (!zrec) zv.store(q.z + o);
                 zv.store(q.eps + o);
-            }, p.rowc, P0, &np);
+            }, p.rowc, P0, &np, gate_init);
         if (rv0 > 0) return rv0;
         np0 = np;
     }
@@ -1387,7 +1380,7 @@ _Pragma("unroll")
                     gate_mult.kind = 1; gate_mult.part = gp; gate_mult.np = gn; gate_mult.out = &st->slots[0]; cur = 0;
                 }
                 else { gate_mult.kind = 4; gate_mult.in = &st->slots[cur]; }
-                gate_mult.eps10 = (double)eps10; gate_mult.f32 = f32;
+                gate_mult.eps10 = (double)eps10; gate_mult.f32 = f32; gate_mult.zcap = zcap;
                 rcv = launch_stencil7_halo<T, 1>(WL_K_PCG_MULT, p.g, p.eps, SrcArray<T>{p.eps}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
                     [=] __device__(long o, int, int, int, const VA &ae, const VA &ec, const VA &, const VA &, const auto &, double *acc, const Pre &) {
                     if (!zst) ae.store(q.z + o);
@@ -1443,7 +1436,7 @@ _Pragma("unroll")
             WL_TRY(ready(gp, gn));
             gate_upd.kind = 2; gate_upd.part = gp; gate_upd.np = gn; gate_upd.in = &st->slots[cur]; gate_upd.out = &st->slots[cur ^ 1];
         }
-        gate_upd.eps10 = (double)eps10; gate_upd.f32 = f32;
+        gate_upd.eps10 = (double)eps10; gate_upd.f32 = f32; gate_upd.zcap = zcap;
         if constexpr (D == 3) {
             if (zst) {   // 7-point kernel over eps: Ae == the z the mult kernel would have stored; a = r, b = x (when x is due)
                 auto upd_epi = [=] __device__(long o, int i, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, const auto &rk, double *acc, const Pre &pre) {
@@ -1566,7 +1559,7 @@ _Pragma("unroll")
             WL_TRY(ready(gp, gn));
             gate_dir.kind = 3; gate_dir.part = gp; gate_dir.np = gn; gate_dir.in = &st->slots[cur]; gate_dir.out = &st->slots[cur ^ 1]; gate_dir.also_x = 1;
         }
-        gate_dir.eps10 = (double)eps10; gate_dir.f32 = f32;
+        gate_dir.eps10 = (double)eps10; gate_dir.f32 = f32; gate_dir.zcap = zcap;
         if (vec) {
             struct DD { VA e, x, z; };
             rvd = launch_rowvec<T, 0, true>(WL_K_PCG_DIR, p.g,

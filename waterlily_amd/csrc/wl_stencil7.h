@@ -65,9 +65,6 @@ template <class T> struct VecA {   // array view of a 16-B vector
 };
 
 constexpr int S7_BY = 4;   // wavefronts per workgroup of the vector kernels
-#ifndef WL_ROWVEC_DEPTH
-#define WL_ROWVEC_DEPTH 1  // planes the streaming kernel k_rowvec requests ahead of the one it works on (1 or 2)
-#endif
 
 // Device-side gate and scalars of a solver kernel, read ONCE per thread before its z loop (uniform addresses): inside
 // the loop they would be re-loaded every plane (the stores in between may alias them as far as the compiler knows),
@@ -95,7 +92,12 @@ struct Gate {
     int also_x = 0;                 // run also when only the deferred x update is owed (direction kernel)
     int inv = 0;                    // kind 0: the body runs when *active == 0 instead
     int rev = 0;                    // every XCD walks its range of tiles backwards (set by the launchers, see sweep_rev)
+    int zcap = 0;                   // host side: > 0 = cut z into at most this many chunks (few partials for the consumer's sum)
 };
+// budget of per-workgroup partials a pcg! kernel may sum itself (Gate kind 1..3): the grid of the kernels of such a call is
+// capped at this many workgroups (swept in round 3 on a 128^3 level: 517 / 326 / 228 / 195 / 232 us per pcg! call for
+// 128 / 256 / 512 / 1024 / 2048)
+constexpr int WL_PCG_PARTIALS = 1024;
 struct Pre { int act; double s0, s1; };
 // pcg!'s scalar logic, shared by the in-kernel form (gate_open) and the k_finalize epilogues of op_pcg
 __device__ __forceinline__ double pcg_rnd(double x, int f32) { return f32 ? (double)(float)x : x; }
@@ -503,27 +505,6 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, LD ld, ST st, const T *rowc
             else st(col + g.s[2] * k, i, j, k, cur, rkc, acc, pre);
         };
         auto rkl = [&](int k) { return RK ? rowk_load<T>(rowc, j + n1 * k) : rowk_none<T>(); };
-#if WL_ROWVEC_DEPTH == 2
-        // THREE operand sets rotate (loop unrolled by three): the operands of plane k+2 are requested before plane k is
-        // worked on -- two planes of every stream in flight per wavefront.  The streaming kernels are short of bytes in flight,
-        // not of issue slots or registers (rocprofv3 SQ counters, DESIGN.md section 4: 50-70 % of their wave cycles parked on
-        // s_waitcnt at 16-74 VGPRs), and what they reach follows what they keep in flight per CU: 32 KB -> 5.1 TB/s
-        // (scale), 48 KB -> 5.6 (pcg update), 96 KB -> 5.9 (pcg direction).
-        const int kl = k1 - 1;
-        Dat d0 = ld(col + g.s[2] * k0, j, k0, pre), d1 = ld(col + g.s[2] * min(k0 + 1, kl), j, min(k0 + 1, kl), pre), d2;
-        RowK<T> r0 = rkl(k0), r1 = rkl(min(k0 + 1, kl)), r2 = rowk_none<T>();
-        auto step = [&](int k, const Dat &cur, const RowK<T> &rkc, Dat &nxt, RowK<T> &rkn) {
-            const int kn = min(k + 2, kl);
-            nxt = ld(col + g.s[2] * kn, j, kn, pre);
-            rkn = rkl(kn);
-            consume(k, cur, rkc);
-        };
-        for (int k = k0; k < k1; k += 3) {
-            step(k, d0, r0, d2, r2);
-            if (k + 1 < k1) step(k + 1, d1, r1, d0, r0);
-            if (k + 2 < k1) step(k + 2, d2, r2, d1, r1);
-        }
-#else
         // two operand sets alternate (loop unrolled by two): a set is never copied while its loads are outstanding
         Dat dA = ld(col + g.s[2] * k0, j, k0, pre), dB;
         RowK<T> rkA = rkl(k0), rkB = rowk_none<T>();
@@ -537,7 +518,6 @@ __global__ __launch_bounds__(256) void k_rowvec(G g, LD ld, ST st, const T *rowc
             step(k, dA, rkA, dB, rkB);
             if (k + 1 < k1) step(k + 1, dB, rkB, dA, rkA);
         }
-#endif
     }
     if (NRED > 0) {
         block_red<(NRED > 0 ? NRED : 1), 4>(acc, OP);
@@ -579,7 +559,7 @@ inline int launch_rowvec(int kclass, const G &g, LD ld, ST st, const T *rowc, do
     const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + 3) / 4;
     const int tpp = ((ntx * nty + 7) / 8) * 8;
     int clen, nchunk;
-    chunking(tpp, R.hi[2] - R.lo[2] + 1, ctx().opt[12], ctx().opt[17], &clen, &nchunk);
+    chunking(tpp, R.hi[2] - R.lo[2] + 1, gate.zcap, ctx().opt[17], &clen, &nchunk);
     const int nblk = tpp * nchunk;
     if (nblk > WL_MAXB) return -1;
     if (np) *np = nblk;
@@ -659,7 +639,7 @@ inline int launch_stencil7_r(int kclass, const G &g, SRC src, const T *L, const 
     const int ntx = (g.n[0] - 2 + 64 * V - 1) / (64 * V), nty = (g.n[1] - 2 + S7_BY * R - 1) / (S7_BY * R);
     const int tpp = ((ntx * nty + 7) / 8) * 8;
     int clen, nchunk;
-    chunking(tpp, khi - klo + 1, ctx().opt[11], ctx().opt[16], &clen, &nchunk);
+    chunking(tpp, khi - klo + 1, gate.zcap, ctx().opt[16], &clen, &nchunk);
     const int nblk = tpp * nchunk;
     if (nblk > WL_MAXB) return -1;   // plane too large for the partial buffer: caller falls back
     if (np) *np = nblk;

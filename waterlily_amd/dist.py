@@ -231,10 +231,12 @@ def init_mailbox(group=None) -> bool:
     if all(oks):
         # self-test before the run depends on it: one all-reduce of the rank numbers with a short bound on the waits; any
         # rank that sees a wrong sum or a time-out votes the mailbox off for everybody
-        L.wl_set_option(26, 3000)
+        keep = C.c_int()
+        _lib.check(L.wl_get_option(26, C.byref(keep)))       # (the caller's bound comes back after the test)
+        L.wl_set_option(26, 10)
         v = (C.c_double * 1)(float(rank + 1))
         good = int(L.wl_allreduce(v, 1, 0) == 0 and v[0] == dist.get_world_size(group) * (dist.get_world_size(group) + 1) / 2)
-        L.wl_set_option(26, 40000)
+        L.wl_set_option(26, keep.value)
         dist.all_gather_object(oks, good, group=group)
     if not all(oks):                                  # all or nothing: every rank must take the same path
         _lib.check(L.wl_comm_mailbox_off())

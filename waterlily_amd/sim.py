@@ -543,6 +543,12 @@ def set_option(key: int, value: int):
     check(_lib.lib().wl_set_option(int(key), int(value)))
 
 
+def get_option(key: int) -> int:
+    v = C.c_int()
+    check(_lib.lib().wl_get_option(int(key), C.byref(v)))
+    return v.value
+
+
 def pcg(p, it=6, level=0) -> int:
     n = C.c_int()
     check(_lib.lib().wl_mg_pcg(p._h, level, it, C.byref(n)))
