@@ -66,6 +66,11 @@ int wl_free(void *p);
 int wl_h2d(void *dst, const void *src, size_t bytes);
 int wl_d2h(void *dst, const void *src, size_t bytes);
 int wl_memset0(void *p, size_t bytes);
+/* the same copies between a dense host array and a PITCHED device array (rows of `width` bytes, `height` of them: every x-row of
+ * every plane and component): how a host keeps the reference's dense arrays on its side (`Array(a)`, `copyto!`) while the
+ * device rows sit on 128-byte boundaries -- the layout the kernels are 5 % faster on */
+int wl_h2d_2d(void *dst_dev, size_t dpitch, const void *src_host, size_t spitch, size_t width, size_t height);
+int wl_d2h_2d(void *dst_host, size_t dpitch, const void *src_dev, size_t spitch, size_t width, size_t height);
 
 /* ------------------------------------------------------------------ multi-GPU communicator (one per process)
  * z-slab decomposition, one process per GPU.  Production: RCCL over xGMI -- rank 0 calls
@@ -190,8 +195,9 @@ int wl_mg_solve(wl_mg *m, double tol, int itmx, int *n_iter);
  * src/MultiLevelPoisson.jl:90,94; macro and file format: src/util.jl:4-24).  wl_mg_log(m, 1) makes every later
  * wl_mg_solve / wl_project / wl_mom_step on this hierarchy record one row {n, L∞(p), L₂(p)} for the initial residual
  * (n = 0) and for each iteration -- two extra reductions and a host synchronisation per row, so it is off by default.
- * wl_mg_log_read copies up to `cap` rows (3 doubles each, oldest first) into `rows`, returns the number of rows
- * recorded since the last read in *n (which may exceed cap) and clears the record.  The host prints the "p" / "c"
+ * wl_mg_log_read copies up to `cap` rows (3 doubles each, oldest first) into `rows` and removes
+ * them from the record; *n receives the number of rows that were waiting (rows beyond cap stay for the next read; cap = 0 is a
+ * query that consumes nothing).  The host prints the "p" / "c"
  * prefixes of src/Flow.jl:158,165 itself. */
 int wl_mg_log(wl_mg *m, int on);
 int wl_mg_log_read(wl_mg *m, double *rows, int cap, int *n);

@@ -42,36 +42,53 @@ mask(perdir) = Cint(reduce(|, (1 << (j - 1) for j in perdir); init=0))        # 
 d3(A) = Cdouble[A..., 0, 0][1:3]
 
 # ---------------------------------------------------------------------------------------------- device array
-"""Dense column-major device array (the reference layout, src/Flow.jl:112-118) owning memory from `wl_malloc`."""
+"""Device array owning memory from `wl_malloc`.  To Julia it is the reference's dense column-major array (src/Flow.jl:112-118:
+`Array(a)`, `copyto!`, `similar`, `size`); on the device every x-row (first index) is PITCHED: its stride is rounded up to 128
+bytes and the allocation is shifted so that the first interior element `a[2,j,k,...]` of every row sits on a 128-byte boundary
+-- the layout the library's 16-byte vector kernels run 5 % faster on than on dense rows of `N+2` elements (bench.py,
+`layout_dense`).  Host copies are pitched 2-D copies (`wl_h2d_2d` / `wl_d2h_2d`): the padding never reaches Julia."""
 mutable struct HIPArray{T,N} <: AbstractArray{T,N}
-    ptr::Ptr{T}
+    base::Ptr{T}              # what wl_malloc returned (freed by the finalizer)
+    ptr::Ptr{T}               # element [1,1,...]: base + lead
     dims::NTuple{N,Int}
+    pitch::Int                # elements between consecutive x-rows (>= dims[1], a multiple of 128 bytes)
     function HIPArray{T,N}(dims::NTuple{N,Int}) where {T,N}
+        al = 128 ÷ sizeof(T)
+        pitch = cld(max(dims[1], 1), al) * al
+        lead = al - 1                                            # element [2,...] of a row lands on the boundary
         p = Ref{Ptr{Cvoid}}()
-        chk(ccall((:wl_malloc, lib), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, max(1, prod(dims)) * sizeof(T)))
-        a = new{T,N}(Ptr{T}(p[]), dims)
-        finalizer(x -> ccall((:wl_free, lib), Cint, (Ptr{Cvoid},), x.ptr), a)
+        bytes = (lead + pitch * max(1, prod(dims[2:end])) + al) * sizeof(T)
+        chk(ccall((:wl_malloc, lib), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, bytes))
+        chk(ccall((:wl_memset0, lib), Cint, (Ptr{Cvoid}, Csize_t), p[], bytes))   # (the row padding is never read; keep it defined)
+        a = new{T,N}(Ptr{T}(p[]), Ptr{T}(p[]) + lead * sizeof(T), dims, pitch)
+        finalizer(x -> ccall((:wl_free, lib), Cint, (Ptr{Cvoid},), x.base), a)
     end
 end
+rows(a::HIPArray) = max(1, prod(a.dims[2:end]))
 HIPArray(h::Array{T,N}) where {T,N} = copyto!(HIPArray{T,N}(size(h)), h)       # `zeros(T,Nd) |> mem` (Flow.jl:114-118)
 Base.size(a::HIPArray) = a.dims
 Base.similar(a::HIPArray{T}, ::Type{S}=T, dims::Dims=a.dims) where {T,S} = HIPArray{S,length(dims)}(dims)
-Base.copyto!(d::HIPArray{T}, h::Array{T}) where T =
-    (chk(ccall((:wl_h2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), d.ptr, h, sizeof(h))); d)
+Base.copyto!(d::HIPArray{T}, h::Array{T}) where T =                                             # dense host rows -> pitched device rows
+    (chk(ccall((:wl_h2d_2d, lib), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cvoid}, Csize_t, Csize_t, Csize_t),
+               d.ptr, d.pitch * sizeof(T), h, d.dims[1] * sizeof(T), d.dims[1] * sizeof(T), rows(d))); d)
 Base.copyto!(h::Array{T}, d::HIPArray{T}) where T =
-    (chk(ccall((:wl_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), h, d.ptr, sizeof(h))); h)
+    (chk(ccall((:wl_d2h_2d, lib), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cvoid}, Csize_t, Csize_t, Csize_t),
+               h, d.dims[1] * sizeof(T), d.ptr, d.pitch * sizeof(T), d.dims[1] * sizeof(T), rows(d))); h)
 Base.Array(a::HIPArray{T,N}) where {T,N} = copyto!(Array{T,N}(undef, a.dims), a)
 Base.copy(a::HIPArray) = HIPArray(Array(a))
 Base.fill!(a::HIPArray{T}, v) where T = iszero(v) ?
-    (chk(ccall((:wl_memset0, lib), Cint, (Ptr{Cvoid}, Csize_t), a.ptr, sizeof(T) * length(a))); a) : copyto!(a, fill(T(v), size(a)))
+    (chk(ccall((:wl_memset0, lib), Cint, (Ptr{Cvoid}, Csize_t), a.ptr, sizeof(T) * a.pitch * rows(a))); a) : copyto!(a, fill(T(v), size(a)))
+# element offset of a[I...]: the first index runs along a row, all the others count rows
+offset(a::HIPArray{T,N}, I::Vararg{Int,N}) where {T,N} = (I[1] - 1) + a.pitch * (N > 1 ? LinearIndices(a.dims[2:end])[I[2:end]...] - 1 : 0)
+offset(a::HIPArray, i::Int) = offset(a, Tuple(CartesianIndices(a.dims)[i])...)               # linear index
 # scalar access = one-element transfers: correct, slow -- only what generic serial code (`julia -t 1` @loop bodies,
 # tests in GPUArrays.@allowscalar style) falls back to
 function Base.getindex(a::HIPArray{T}, I::Vararg{Int}) where T
-    r = Ref{T}(); o = LinearIndices(a.dims)[I...] - 1
+    r = Ref{T}(); o = offset(a, I...)
     chk(ccall((:wl_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), r, a.ptr + o * sizeof(T), sizeof(T))); r[]
 end
 function Base.setindex!(a::HIPArray{T}, v, I::Vararg{Int}) where T
-    r = Ref{T}(T(v)); o = LinearIndices(a.dims)[I...] - 1
+    r = Ref{T}(T(v)); o = offset(a, I...)
     chk(ccall((:wl_h2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), a.ptr + o * sizeof(T), r, sizeof(T))); a
 end
 Base.getindex(a::HIPArray, I::CartesianIndex) = a[Tuple(I)...]
@@ -126,8 +143,9 @@ function (k::KernelAbstractions.Kernel{HostStaged})(args...; ndrange=nothing, wo
     nothing
 end
 
+# wl_grid of a field whose first D axes are spatial (trailing axes: components, one pitched block of rows each)
 grid(a::HIPArray, D=ndims(a)) = (n = (size(a)[1:D]..., ntuple(_ -> 1, 3 - D)...);
-    WlGrid(D, Int32.(n), (1, n[1], n[1] * n[2]), prod(n), 0, 0, 0, 0, 0))
+    WlGrid(D, Int32.(n), (1, a.pitch, a.pitch * n[2]), a.pitch * n[2] * n[3], 0, 0, 0, 0, 0))
 
 # ---------------------------------------------------------------------------------------------- util.jl
 BC!(a::HIPArray{T}, A, saveexit=false, perdir=()) where T =                                  # src/util.jl:192-210
@@ -231,9 +249,11 @@ restrictL!(a::HIPArray{T}, b::HIPArray{T}; perdir=()) where T =                 
 # reference's format (Poisson.jl:164,167; MultiLevelPoisson.jl:90,94)
 logging_on() = Base.CoreLogging.min_enabled_level(Base.CoreLogging.current_logger()) <= WaterLily._psolver
 function emit_log(h)
-    n = Ref{Cint}(); rows = zeros(Cdouble, 3 * 64)
-    chk(ccall((:wl_mg_log_read, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), h, rows, 64, n))
-    for q in 1:min(n[], 64)
+    n = Ref{Cint}()
+    chk(ccall((:wl_mg_log_read, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), h, C_NULL, 0, n))   # cap 0: how many rows wait
+    rows = zeros(Cdouble, 3 * max(n[], 1))
+    chk(ccall((:wl_mg_log_read, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), h, rows, n[], n))
+    for q in 1:n[]
         @log ", $(Int(rows[3q-2])), $(rows[3q-1]), $(rows[3q])\n"
     end
 end
@@ -266,10 +286,12 @@ function mom_step!(a::Flow{N,T,<:HIPArray}, b::AbstractPoisson) where {N,T}     
     chk(ccall((:wl_mom_step, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
               Ref{Cdouble}, Ptr{Cint}), handle(a), hb, a.Δt[end], U, gp, gc, dt, n2))
     if lg   # the rows of the predictor's solve, then the corrector's: each starts with n = 0 (`@log "p"` / `@log "c"`, Flow.jl:158,165)
-        n = Ref{Cint}(); rows = zeros(Cdouble, 3 * 80)
-        chk(ccall((:wl_mg_log_read, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), hb, rows, 80, n))
+        n = Ref{Cint}()
+        chk(ccall((:wl_mg_log_read, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), hb, C_NULL, 0, n))   # how many rows wait
+        rows = zeros(Cdouble, 3 * max(n[], 1))
+        chk(ccall((:wl_mg_log_read, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), hb, rows, n[], n))
         tag = ("p", "c"); k = 0
-        for q in 1:min(n[], 80)
+        for q in 1:n[]
             rows[3q-2] == 0 && (k += 1; @log tag[min(k, 2)])
             @log ", $(Int(rows[3q-2])), $(rows[3q-1]), $(rows[3q])\n"
         end
@@ -388,32 +410,49 @@ One process per GPU.  Rank 0 draws the RCCL unique id, `bcast(::Vector{UInt8})` 
 `grid` carries the slab fields (`slab_grid`) runs the z-slab path: halo exchanges (ncclSend/ncclRecv on the library's comm
 stream), one ncclAllReduce per dot product, ncclAllGather at the hand-over to the replicated coarse levels.
 """
-function init_slabs!(bcast, rank::Integer, nranks::Integer; device=rank)
+function init_slabs!(bcast, rank::Integer, nranks::Integer; device=rank, allmin=nothing)
     chk(ccall((:wl_set_device, lib), Cint, (Cint,), device))
     id = zeros(UInt8, 128)
     rank == 0 && chk(ccall((:wl_comm_unique_id, lib), Cint, (Ptr{UInt8},), id))
     bcast(id)
     chk(ccall((:wl_comm_init_rccl, lib), Cint, (Ptr{UInt8}, Cint, Cint), id, rank, nranks))
-    # scalars (dot products, CFL maximum, force sums) through the shared-memory mailbox instead of one ncclAllReduce each:
-    # rank 0 creates the POSIX shared-memory object, the others open it after the broadcast has ordered them behind it
+    # Scalars (dot products, CFL maximum, force sums) through the shared-memory mailbox instead of one ncclAllReduce each --
+    # only when the caller supplies `allmin(x::Int)`, the minimum of x over the ranks (e.g. x -> MPI.Allreduce(x, MPI.MIN, comm)):
+    # a true synchronisation AND the all-or-nothing vote.  (A broadcast is neither: its root may return before the others
+    # have even entered it.)  Without it the scalars stay on ncclAllReduce.
+    allmin === nothing && return
     name = zeros(UInt8, 64)
+    ok = 1
     if rank == 0
         nm = "/wlhip-$(getpid())-$(rand(UInt32))"
         copyto!(name, 1, codeunits(nm), 1, ncodeunits(nm))
-        chk(ccall((:wl_comm_mailbox, lib), Cint, (Cstring, Cint), nm, 1))
+        ok = ccall((:wl_comm_mailbox, lib), Cint, (Cstring, Cint), nm, 1) == 0 ? 1 : 0
     end
-    bcast(name)                                        # (a broadcast completes on rank r only after rank 0 entered it: created first)
+    bcast(name)                                        # the name exists before anybody else looks for it (rank 0 created it first)
     nm = unsafe_string(pointer(name))
-    rank == 0 || chk(ccall((:wl_comm_mailbox, lib), Cint, (Cstring, Cint), nm, 0))
-    bcast(name)                                        # everybody has mapped it: the name can go
-    rank == 0 && rm("/dev/shm" * nm; force=true)
+    rank == 0 || (ok = ccall((:wl_comm_mailbox, lib), Cint, (Cstring, Cint), nm, 0) == 0 ? 1 : 0)
+    ok = allmin(ok)                                    # everybody has tried to map it, and everybody knows whether all succeeded
+    rank == 0 && rm("/dev/shm" * nm; force=true)       # (the mappings keep the memory alive)
+    if ok == 1                                         # self-test with a short bound before the run depends on it
+        keep = Ref{Cint}()
+        chk(ccall((:wl_get_option, lib), Cint, (Cint, Ref{Cint}), 26, keep))
+        chk(ccall((:wl_set_option, lib), Cint, (Cint, Cint), 26, 10))
+        v = Cdouble[rank + 1]
+        good = ccall((:wl_allreduce, lib), Cint, (Ptr{Cdouble}, Cint, Cint), v, 1, 0) == 0 && v[1] == nranks * (nranks + 1) / 2
+        chk(ccall((:wl_set_option, lib), Cint, (Cint, Cint), 26, keep[]))
+        ok = allmin(good ? 1 : 0)
+    end
+    ok == 1 || chk(ccall((:wl_comm_mailbox_off, lib), Cint, ()))   # all or nothing: every rank takes the same path
+    nothing
 end
 finalize_slabs!() = chk(ccall((:wl_comm_finalize, lib), Cint, ()))
-"""wl_grid of rank `r`'s z-slab of an undecomposed array of extents `Ng` (ghosts included): nz/P interior planes + 2 halo
-planes per side (QUICK reads I-2δ..I+δ, src/Flow.jl:6); rank 0 owns the lower ghost plane, rank P-1 the upper one."""
-function slab_grid(Ng::NTuple{3,Int}, r, P; ring=false)
+"""wl_grid of rank `r`'s z-slab `a` (local extents `(Ng[1], Ng[2], nz/P + 4)`) of an undecomposed array of extents `Ng`
+(ghosts included): nz/P interior planes + 2 halo planes per side (QUICK reads I-2δ..I+δ, src/Flow.jl:6); rank 0 owns the
+lower ghost plane, rank P-1 the upper one."""
+function slab_grid(a::HIPArray, Ng::NTuple{3,Int}, r, P; ring=false)
     nzl = (Ng[3] - 2) ÷ P; n = (Ng[1], Ng[2], nzl + 4)
-    WlGrid(3, Int32.(n), (1, n[1], n[1] * n[2]), prod(n), Ng[3], r * nzl + 1 - 2, 2 - ((r == 0 && !ring) ? 1 : 0),
+    @assert size(a)[1:3] == n
+    WlGrid(3, Int32.(n), (1, a.pitch, a.pitch * n[2]), a.pitch * n[2] * n[3], Ng[3], r * nzl + 1 - 2, 2 - ((r == 0 && !ring) ? 1 : 0),
            2 + nzl - 1 + ((r == P - 1 && !ring) ? 1 : 0), ring)
 end
 

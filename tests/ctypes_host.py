@@ -5,8 +5,8 @@ This is what `julia/WaterLilyHIPNativeExt.jl` does (lines cited per step) writte
 library has to own its HIP context, its allocations and its stream -- no torch creates the context, hands over memory or
 sets the current device.  (Every other GPU test lets torch do those three things.)
 
-    HIPArray(zeros(T, Nd))           -> wl_malloc + wl_h2d           (shim :46-57;  src/Flow.jl:114-118 `zeros(T,Nd) |> f`)
-    Flow / MultiLevelPoisson         -> wl_flow_create, wl_mg_create  (shim :178-200; dense strides, pitch N+2)
+    HIPArray(zeros(T, Nd))           -> wl_malloc + wl_memset0 + wl_h2d_2d  (shim `HIPArray`; src/Flow.jl:114-118 `zeros(T,Nd) |> f`)
+    Flow / MultiLevelPoisson         -> wl_flow_create, wl_mg_create  (shim `handle`; strides from the array's pitch)
     measure!(flow, body) epilogue    -> wl_flow_update, wl_mg_update  (src/Body.jl:31-53, src/MultiLevelPoisson.jl:62-68)
     mom_step!(flow, pois)            -> wl_mom_step                   (shim :260-280; src/Flow.jl:153-169)
     pressure_force(sim)              -> wl_pforce                     (src/Metrics.jl:94-100)
@@ -15,6 +15,12 @@ sets the current device.  (Every other GPU test lets torch do those three things
 Inputs and expected outputs: tests/golden/sim_*.npz (coefficient fields measured by the oracle's geometry, initial velocity,
 u / p / pois.n / dt / force after `nsteps` steps).  The body term of pressure_force (n̂·kern, Metrics.jl:84-87: a user
 closure in the reference, evaluated on the host side of the ABI) comes from oracle/geometry.py -- test infrastructure.
+
+Two layouts: "pitched" (default: what the shim's HIPArray allocates -- row stride rounded up to 128 bytes, first interior element
+of every row on a 128-byte boundary, host copies by wl_h2d_2d / wl_d2h_2d) and "dense" (the reference's own strides, pitch N+2,
+plain wl_h2d / wl_d2h).
+
+    python tests/ctypes_host.py sim_3d_f32 [pitched|dense] [libwlhip.so]
 
 Prints one JSON line; exit code 0 = every comparison passed.  `import torch` never happens (asserted at the end)."""
 import ctypes as C
@@ -42,7 +48,7 @@ class FlowDesc(C.Structure):  # wl_flow_desc
         ("nu", C.c_double), ("exitBC", C.c_int32), ("perdir_mask", C.c_int32)]
 
 
-def main(name, lib_path):
+def main(name, lib_path, layout="pitched"):
     L = C.CDLL(lib_path)
     L.wl_last_error.restype = C.c_char_p
 
@@ -63,34 +69,64 @@ def main(name, lib_path):
     wlt = 0 if T == np.float32 else 1
     owned = []
 
-    def dense_grid(Ng):   # the Julia layout: column-major, no padding
+    al = 128 // T.itemsize
+    for fn in ("wl_h2d_2d", "wl_d2h_2d"):
+        getattr(L, fn).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
+
+    def pitch_of(n0):     # elements between consecutive x-rows
+        return n0 if layout == "dense" else -(-n0 // al) * al
+
+    def field_grid(Ng):   # wl_grid of a field of spatial extents Ng (components: one block of rows each)
         gr = Grid()
         n = tuple(Ng) + (1,) * (3 - D)
+        pt = pitch_of(n[0])
         gr.D = D
         gr.n[:] = n
-        gr.s[:] = (1, n[0], n[0] * n[1])
-        gr.sc = n[0] * n[1] * n[2]
+        gr.s[:] = (1, pt, pt * n[1])
+        gr.sc = pt * n[1] * n[2]
         return gr
 
-    def device(h, order="F"):        # HIPArray(h::Array): column-major like Julia (order="C": a row-major table)
-        h = np.asfortranarray(h) if order == "F" else np.ascontiguousarray(h)
+    def alloc(shape):     # HIPArray{T,N}(dims): zeroed; returns the pointer to element [1,1,...]
+        rows = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        lead = 0 if layout == "dense" else al - 1
+        nb = (lead + pitch_of(shape[0]) * rows + al) * T.itemsize
+        base = C.c_void_p()
+        chk(L.wl_malloc(C.byref(base), C.c_size_t(nb)), "wl_malloc")
+        chk(L.wl_memset0(base, C.c_size_t(nb)), "wl_memset0")
+        owned.append(base)
+        p = C.c_void_p(base.value + lead * T.itemsize)
+        assert layout == "dense" or (p.value + T.itemsize) % 128 == 0       # the first interior element of a row is aligned
+        return p
+
+    def device(h):        # HIPArray(h::Array): copyto!(HIPArray(size(h)), h)
+        h = np.asfortranarray(h, dtype=T)
+        p = alloc(h.shape)
+        rows = int(np.prod(h.shape[1:]))
+        w = h.shape[0] * T.itemsize
+        if layout == "dense":
+            chk(L.wl_h2d(p, h.ctypes.data_as(C.c_void_p), C.c_size_t(h.nbytes)), "wl_h2d")
+        else:
+            chk(L.wl_h2d_2d(p, pitch_of(h.shape[0]) * T.itemsize, h.ctypes.data_as(C.c_void_p), w, w, rows), "wl_h2d_2d")
+        return p
+
+    def table(h):         # a plain device buffer (band indices, n*kern vectors): no rows, no pitch
+        h = np.ascontiguousarray(h)
         p = C.c_void_p()
         chk(L.wl_malloc(C.byref(p), C.c_size_t(max(1, h.nbytes))), "wl_malloc")
         chk(L.wl_h2d(p, h.ctypes.data_as(C.c_void_p), C.c_size_t(h.nbytes)), "wl_h2d")
         owned.append(p)
         return p
 
-    def zeros(shape):     # fill!(similar(x), 0)
-        nb = int(np.prod(shape)) * T.itemsize
-        p = C.c_void_p()
-        chk(L.wl_malloc(C.byref(p), C.c_size_t(nb)), "wl_malloc")
-        chk(L.wl_memset0(p, C.c_size_t(nb)), "wl_memset0")
-        owned.append(p)
-        return p
+    zeros = alloc          # fill!(similar(x), 0)
 
     def host(p, shape):   # Array(a::HIPArray)
         h = np.empty(shape, dtype=T, order="F")
-        chk(L.wl_d2h(h.ctypes.data_as(C.c_void_p), p, C.c_size_t(h.nbytes)), "wl_d2h")
+        rows = int(np.prod(shape[1:]))
+        w = shape[0] * T.itemsize
+        if layout == "dense":
+            chk(L.wl_d2h(h.ctypes.data_as(C.c_void_p), p, C.c_size_t(h.nbytes)), "wl_d2h")
+        else:
+            chk(L.wl_d2h_2d(h.ctypes.data_as(C.c_void_p), w, p, pitch_of(shape[0]) * T.itemsize, w, rows), "wl_d2h_2d")
         return h
 
     Ng = tuple(n + 2 for n in dims)
@@ -99,7 +135,7 @@ def main(name, lib_path):
     f, p, sigma = zeros(Ng + (D,)), zeros(Ng), zeros(Ng)
     V, mu0, mu1 = device(g["V"]), device(g["mu0"]), device(g["mu1"])
     fd = FlowDesc()
-    fd.g = dense_grid(Ng)
+    fd.g = field_grid(Ng)
     for k, v in (("u", u), ("u0", u0), ("f", f), ("p", p), ("sigma", sigma), ("V", V), ("mu0", mu0), ("mu1", mu1)):
         setattr(fd, k, v)
     m = dims[-1]
@@ -114,7 +150,7 @@ def main(name, lib_path):
         shapes.append(tuple(1 + n // 2 for n in shapes[-1]))
     levels = (Level * len(shapes))()
     for l, sh in enumerate(shapes):
-        levels[l].g = dense_grid(sh)
+        levels[l].g = field_grid(sh)
         if l == 0:
             levels[l].x, levels[l].L, levels[l].z = p, mu0, sigma          # aliasing, src/WaterLily.jl:77
         else:
@@ -140,12 +176,14 @@ def main(name, lib_path):
     # pressure_force: the body term from the checker's geometry, the integral in the library
     from oracle import geometry as G
     idx, nds = G.nds_band(G.Body(G.Sphere(m / 2 - 1, R)), dims, t=0.0)
-    idx = np.ascontiguousarray(idx, dtype=np.int64)        # dense column-major cell index == element offset in the dense layout
+    sub = np.unravel_index(np.asarray(idx, dtype=np.int64), Ng, order="F")       # dense cell index -> element offset in the field
+    strides = (1, pitch_of(Ng[0]), pitch_of(Ng[0]) * Ng[1])
+    idx = np.ascontiguousarray(sum(q.astype(np.int64) * st for q, st in zip(sub, strides)), dtype=np.int64)
     nds = np.ascontiguousarray(nds, dtype=np.float64)
     L.wl_pforce.argtypes = [C.c_int, C.POINTER(Grid), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]
     force = (C.c_double * 3)()
-    gr = dense_grid(Ng)
-    chk(L.wl_pforce(wlt, C.byref(gr), p, device(idx), device(nds, "C"), len(idx), force), "wl_pforce")   # nds[b*D + c]
+    gr = field_grid(Ng)
+    chk(L.wl_pforce(wlt, C.byref(gr), p, table(idx), table(nds), len(idx), force), "wl_pforce")   # nds[b*D + c]
 
     uh, ph = host(u, Ng + (D,)), host(p, Ng)
     chk(L.wl_mg_destroy(mg), "wl_mg_destroy")
@@ -156,7 +194,7 @@ def main(name, lib_path):
     f32 = T == np.float32
     tol = 5e-4 if f32 else 1e-10          # the tolerances of tests/test_golden.py::test_hip_sim_golden
     res = {
-        "case": name, "n": ns, "n_expected": [int(v) for v in g["n"]],
+        "case": name, "layout": layout, "n": ns, "n_expected": [int(v) for v in g["n"]],
         "du": float(np.max(np.abs(uh - g["u"])) / np.max(np.abs(g["u"]))),
         "dp": float(np.max(np.abs(ph - g["p"])) / np.max(np.abs(g["p"]))),
         "ddt": float(np.max(np.abs(np.array(dts) - g["dt"]) / g["dt"])),
@@ -172,4 +210,5 @@ def main(name, lib_path):
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "waterlily_amd", "libwlhip.so")))
+    sys.exit(main(sys.argv[1], sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "waterlily_amd", "libwlhip.so"),
+                  sys.argv[2] if len(sys.argv) > 2 else "pitched"))

@@ -1,7 +1,8 @@
 """The drop-in boundary driven by hosts OTHER than the torch-based test harness:
 
-  * tests/ctypes_host.py -- a torch-free process that follows the Julia shim's call sequence (wl_malloc / wl_h2d / dense strides /
-    wl_flow_create / wl_mg_create / wl_mom_step / wl_pforce / wl_d2h / wl_free): the library owns its context and allocator;
+  * tests/ctypes_host.py -- a torch-free process that follows the Julia shim's call sequence (wl_malloc / wl_h2d_2d / pitched or
+    dense strides / wl_flow_create / wl_mg_create / wl_mom_step / wl_pforce / wl_d2h_2d / wl_free): the library owns its
+    context and allocator;
   * bench.py --gpus N without a launcher around it: the parent starts its ranks as child processes, never touches the GPU,
     relays rank 0's JSON line and the children's status."""
 import json
@@ -66,11 +67,13 @@ def test_bench_parent_stays_off_the_gpu_and_relays_the_ranks_status():
 # ----------------------------------------------------------------------------- GPU
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["pitched", "dense"])
 @pytest.mark.parametrize("name", ["sim_3d_f32", "sim_2d_f64"])
-def test_torch_free_host_reproduces_the_golden_steps(name):
-    """ext/WaterLilyAMDGPUExt.jl's role played through the C ABI alone: memory from wl_malloc, dense Julia strides, handles,
-    steps, force, read-back -- against tests/golden (u, p, pois.n, Δt, pressure force)."""
-    r = subprocess.run([sys.executable, HOST, name], capture_output=True, text=True, env=_env(), timeout=600)
+def test_torch_free_host_reproduces_the_golden_steps(name, layout):
+    """ext/WaterLilyAMDGPUExt.jl's role played through the C ABI alone: memory from wl_malloc, handles, steps, force, read-back
+    -- against tests/golden (u, p, pois.n, Δt, pressure force).  pitched: the shim's HIPArray (rows on 128-byte boundaries,
+    wl_h2d_2d / wl_d2h_2d); dense: the reference's own strides."""
+    r = subprocess.run([sys.executable, HOST, name, layout], capture_output=True, text=True, env=_env(), timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["ok"] and not res["torch_imported"] and res["n"] == res["n_expected"], res
@@ -94,13 +97,15 @@ def test_bench_launches_its_own_ranks():
 
 @pytest.mark.gpu
 def test_bench_loopback_rank_runs_the_slab_of_one_rank():
-    """bench.py --comm loopback: one process plays rank 3 of 8 -- its 1/8 slab with halos, split launches, reductions and
-    (device-copy) exchanges; the collective counters are those of a real rank."""
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--comm", "loopback", "--rank", "3", "--grid", "64", "64", "128",
+    """bench.py --comm loopback: one process plays a rank of 8 (default: the second one, an interior slab the body does not
+    reach) -- its 1/8 slab with halos, split launches, reductions and (device-copy) exchanges; the solver converges as in a
+    real run and the collective counters are those of a real rank."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--comm", "loopback", "--grid", "64", "64", "128",
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=_env(), cwd=ROOT,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
-    assert out["loopback"]["rank"] == 3 and out["loopback"]["of"] == 8 and out["config"]["comm_ranks"] == 8
+    assert out["loopback"]["rank"] == 1 and out["loopback"]["of"] == 8 and out["config"]["comm_ranks"] == 8
+    assert max(out["config"]["vcycles_per_solve"]) <= 3
     cl = out["config"]["collectives_last_step"]
     assert cl["allreduce"] > 0 and cl["exchanges"] > 0 and cl["allgather"] > 0

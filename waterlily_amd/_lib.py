@@ -94,6 +94,8 @@ def lib() -> C.CDLL:
         "wl_h2d": (i, [vp, vp, C.c_size_t]),
         "wl_d2h": (i, [vp, vp, C.c_size_t]),
         "wl_memset0": (i, [vp, C.c_size_t]),
+        "wl_h2d_2d": (i, [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t]),
+        "wl_d2h_2d": (i, [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t]),
         "wl_comm_unique_id": (i, [vp]),
         "wl_comm_init_rccl": (i, [vp, i, i]),
         "wl_comm_init_host": (i, [i, i, SENDRECV_FN, ALLREDUCE_FN, ALLGATHER_FN, vp]),

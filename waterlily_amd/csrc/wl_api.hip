@@ -985,6 +985,18 @@ int wl_d2h(void *dst, const void *src, size_t bytes) {
     return 0;
 }
 int wl_memset0(void *p, size_t bytes) { WL_HIP(hipMemsetAsync(p, 0, bytes, ctx().stream)); return 0; }
+int wl_h2d_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height) {
+    if (width > dpitch || width > spitch) return fail(WL_E_ARG, "wl_h2d_2d: row wider than a pitch", __FILE__, __LINE__);
+    WL_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, ctx().stream));
+    WL_HIP(hipStreamSynchronize(ctx().stream));
+    return 0;
+}
+int wl_d2h_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height) {
+    if (width > dpitch || width > spitch) return fail(WL_E_ARG, "wl_d2h_2d: row wider than a pitch", __FILE__, __LINE__);
+    WL_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, ctx().stream));
+    WL_HIP(hipStreamSynchronize(ctx().stream));
+    return 0;
+}
 
 #define WL_GS()                                  \
     WL_TRY(check_grid(g));                       \
@@ -1210,10 +1222,11 @@ int wl_mg_log(wl_mg *m, int on) {
 int wl_mg_log_read(wl_mg *m, double *rows, int cap, int *n) {
     if (!m || !n || (cap > 0 && !rows)) return fail(WL_E_ARG, "wl_mg_log_read: null argument", __FILE__, __LINE__);
     const int have = (int)(m->log.size() / 3);
-    const int take = have < cap ? have : (cap > 0 ? cap : 0);
-    for (int q = 0; q < 3 * take; ++q) rows[q] = m->log[q];
     *n = have;
-    m->log.clear();
+    if (cap <= 0) return 0;                        // a query: nothing is consumed
+    const int take = have < cap ? have : cap;
+    for (int q = 0; q < 3 * take; ++q) rows[q] = m->log[q];
+    m->log.erase(m->log.begin(), m->log.begin() + 3 * take);   // what did not fit stays for the next read
     return 0;
 }
 int wl_mg_vcycle(wl_mg *m, int level) {

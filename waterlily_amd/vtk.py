@@ -243,7 +243,11 @@ def write(w: VTKWriter, sim) -> None:
         w._check()
     slot.free.clear()
     if slot.buf is None or slot.buf.numel() < nbytes:
-        slot.buf = torch.empty(nbytes, dtype=torch.uint8, device=flow.device)
+        # sized once: every slot of the ring at the first snapshot (an allocation synchronises the device -- none later)
+        torch.cuda.synchronize()
+        for s in w._slots:
+            if s is slot or s.free.is_set():
+                s.buf = torch.empty(nbytes, dtype=torch.uint8, device=flow.device)
     w._start(flow.device)
     for name, a, nc, nct, off, n in fields:
         g = S._grid_of(a, D)
