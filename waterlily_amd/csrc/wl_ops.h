@@ -1270,18 +1270,150 @@ _Pragma("unroll")
 // exit leaves st->xpend so that the direction kernel still applies the owed x update and nothing else.
 // (A variant that folded the direction update into the next mult kernel -- eps_new evaluated on the fly at the 7 stencil
 // points, one array pass less on paper -- was measured slower and removed: see DESIGN.md "measured dead ends".)
+//
+// The function has two independent halves.  WHICH KERNELS run (16-B vector or scalar range kernels; z' stored or
+// recomputed; z = A*eps stored or formed twice) is decided by the switches below.  HOW A DOT PRODUCT IS FINISHED and
+// pcg!'s scalar logic applied (Poisson.jl:127,131-132,135,137-139) is one of three forms, PcgDots:
+//   FINALIZE   a one-workgroup launch after every reducing kernel sums its partials and updates the State; the kernels gate
+//              on st->active (every level when the layout rules out the vector kernels, and the levels above 2^25 cells);
+//   IN_KERNEL  no such launches: the NEXT kernel sums the producer's <= 1024 partials itself in every workgroup and applies the
+//              scalar logic (Gate kind 1..3), the state hops between two slots; one finalize at the end publishes it
+//              (single rank, levels of <= 2^25 cells: -2.8 % per step at 256^3 and below);
+//   SLAB       z-slab levels: the producer's partials are reduced and summed over the ranks (mailbox or ncclAllReduce) into ONE
+//              value, which the consuming kernel's gate treats like a single partial.
+enum class PcgForm { FINALIZE, IN_KERNEL, SLAB };
+template <class T> struct PcgDots {
+    PcgForm form;
+    State *st;
+    double *partials;
+    bool dist, xdef, want_r2;
+    T eps10;
+    int f32, zcap;
+    double *P0, *PA, *PB;   // partials of rho (init) / z.eps (mult) / r.z' or r.r (update); one buffer in the FINALIZE form
+    int cur = 0;            // the slot of st->slots holding the current state (IN_KERNEL, SLAB)
+    PcgDots(PcgForm f, State *st_, double *partials_, bool dist_, bool xdef_, bool want_r2_, T eps10_, int zcap_)
+        : form(f), st(st_), partials(partials_), dist(dist_), xdef(xdef_), want_r2(want_r2_), eps10(eps10_), f32(sizeof(T) == 4), zcap(zcap_) {
+        const bool own = f != PcgForm::FINALIZE;
+        P0 = partials; PA = own ? partials + WL_MAXB : partials; PB = own ? partials + 2 * WL_MAXB : partials;
+    }
+    Gate base() const { Gate g; g.eps10 = (double)eps10; g.f32 = f32; g.zcap = zcap; return g; }
+    // SLAB: the producer's partials become the one value summed over the ranks
+    int ready(const double *&part, int &n) const {
+        if (form != PcgForm::SLAB) return 0;
+        Prof pr(WL_K_SCALAR, 0);
+        WL_TRY((reduce_allreduce<1>(part, n, (int)RED_SUM, 0.0, st->red)));
+        part = st->red;
+        n = 1;
+        return 0;
+    }
+    // ---- after the init kernel (rho = r.z, :126-127)
+    int after_init(int np) const {
+        if (form != PcgForm::FINALIZE) return 0;
+        State *s = st;
+        const T e10 = eps10;
+        return launch_finalize<1>(dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
+            const T rho = (T)v[0];
+            s->rho = (double)rho;
+            s->nupd = 0;
+            s->r2_valid = 0;
+            s->xpend = 0;
+            s->active = !((rho < 0 ? -rho : rho) < e10);
+        });
+    }
+    // ---- the gate of mult number n (it finishes rho when n == 1), then what follows the kernel (alpha, :131-132)
+    int gate_mult(int n, int np0, Gate &g) {
+        g = base();
+        if (form == PcgForm::FINALIZE) { g.active = &st->active; return 0; }
+        if (n == 1) {
+            const double *gp = P0; int gn = np0;
+            WL_TRY(ready(gp, gn));
+            g.kind = 1; g.part = gp; g.np = gn; g.out = &st->slots[0]; cur = 0;
+        } else { g.kind = 4; g.in = &st->slots[cur]; }
+        return 0;
+    }
+    int after_mult(int np) const {
+        if (form != PcgForm::FINALIZE) return 0;
+        State *s = st;
+        return launch_finalize<1>(dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
+            s->xpend = 0;   // any owed x update was applied by the direction kernel before this mult
+            if (!s->active) return;
+            const T alpha = (T)s->rho / (T)v[0];
+            const double aa = (double)(alpha < 0 ? -alpha : alpha);
+            s->alpha = (double)alpha;
+            if (aa < 1e-2 || aa > 1e2) s->active = 0;  // :132
+        });
+    }
+    // ---- the update kernel's gate (it finishes z.eps), then what follows it (rho2 / beta, :135,137-139; r.r after the last)
+    int gate_update(int npA, Gate &g) {
+        g = base();
+        if (form == PcgForm::FINALIZE) { g.active = &st->active; g.s0 = &st->alpha; return 0; }
+        const double *gp = PA; int gn = npA;
+        WL_TRY(ready(gp, gn));
+        g.kind = 2; g.part = gp; g.np = gn; g.in = &st->slots[cur]; g.out = &st->slots[cur ^ 1];
+        return 0;
+    }
+    void launched_update() { if (form != PcgForm::FINALIZE) cur ^= 1; }
+    int after_update(int np, bool last, bool xnow) const {
+        State *s = st;
+        const bool wr2 = want_r2;
+        if (form != PcgForm::FINALIZE) {
+            if (!last) return 0;
+            const int cs = cur;   // the one finalize of the call: finishes r.r (:135) and publishes the state for the host / L2
+            return launch_finalize<1>(dist, PB, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
+                PcgS sl = s->slots[cs];
+                if (sl.active) {
+                    sl.nupd += 1;
+                    if (wr2) { sl.r2 = (double)(T)v[0]; sl.r2_valid = 1; }
+                    sl.active = 0;
+                }
+                s->rho = sl.rho; s->alpha = sl.alpha; s->beta = sl.beta;
+                s->active = sl.active; s->xpend = sl.xpend; s->nupd = sl.nupd;
+                s->r2_valid = sl.r2_valid;
+                if (sl.r2_valid) s->r2 = sl.r2;
+            });
+        }
+        const T e10 = eps10;
+        return launch_finalize<1>(dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
+            if (!s->active) return;
+            s->nupd += 1;
+            if (last) {  // :135
+                if (wr2) { s->r2 = (double)(T)v[0]; s->r2_valid = 1; }
+                s->active = 0;
+                return;
+            }
+            const T rho2 = (T)v[0];
+            if ((rho2 < 0 ? -rho2 : rho2) < e10) { s->active = 0; s->xpend = !xnow; return; }  // :138
+            s->beta = (double)(rho2 / (T)s->rho);
+            s->rho = (double)rho2;
+        });
+    }
+    // ---- the direction kernel's gate (it finishes r.z')
+    int gate_direction(int npB, Gate &g) {
+        g = base();
+        if (form == PcgForm::FINALIZE) {
+            g.active = &st->active; g.also = xdef ? &st->xpend : nullptr; g.s0 = &st->alpha; g.s1 = &st->beta;
+            return 0;
+        }
+        const double *gp = PB; int gn = npB;
+        WL_TRY(ready(gp, gn));
+        g.kind = 3; g.part = gp; g.np = gn; g.in = &st->slots[cur]; g.out = &st->slots[cur ^ 1]; g.also_x = 1;
+        return 0;
+    }
+    void launched_direction() { if (form != PcgForm::FINALIZE) cur ^= 1; }
+};
+
 template <class T, int D>
 int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st, bool want_r2 = false,
            int pre_np = -1,     // pre_np >= 0: eps = r*iD and the partials of rho are already there (op_prolong_increment_fused)
            bool ghost_z = false) {   // z's ghost cells may hold non-zero values (level 1: z is flow.sigma, see op_sigma_ghosts)
     const LevelT<T> q = p;
     const Range R = r_inside(p.g);
-    const T eps10 = (T)10 * Lim<T>::eps;
-    int np = 0;
+    using VA = VecA<T>;
+    const int n0 = p.g.n[0];
+    // ---- which kernels
     // streaming pcg kernels in 16-B vector form where the layout allows (wl_set_option(5,0) = scalar range kernels)
     bool vec = false;
     if constexpr (D == 3) vec = ctx().opt[5] != 0 && stencil7_ok<T>(p.g);
-    using VA = VecA<T>;
     const bool xdef = ctx().opt[8] != 0;
     // z' = r*iD (:136) is not stored (wl_set_option(13), default on): the direction kernel recomputes it from r and iD
     // (iD is a row constant away from the body), one array write + one read less per iteration; z keeps A*eps.
@@ -1290,49 +1422,33 @@ int op_pcg(const LevelT<T> &p, int it, int permask, double *partials, State *st,
     // over eps that forms the same A*eps again (same expression, same operands => same bits) and applies
     // r -= alpha*(A*eps) in its epilogue.  Per iteration one array write (mult) and one array read (update) are replaced
     // by a second read of eps (with its halo rows and planes).  Measured: 512^3 mult 0.303 -> 0.224 ms but update
-    // 0.344 -> 0.449 ms (the 7-point form of the update runs at 4.1 TB/s, with one or two rows per thread): no gain; 256^3 as the finest level: -2.5 % per
+    // 0.344 -> 0.449 ms (the 7-point form of the update runs at 4.1 TB/s): no gain; 256^3 as the finest level: -2.5 % per
     // step; levels of 128^3 cells and below are latency-bound and lose 5-10 % of a pcg! call to the heavier update kernel
-    // (tools/midlevels.py 19=3,0: 194 / 175, 110 / 101, 77 / 72 us).  Default (1): levels of 2^22 .. 2^26 cells; 3 = every level
-    // below 2^26; 2 = every level; 0 = never.
+    // (tools/midlevels.py 19=3,0: 194 / 175, 110 / 101, 77 / 72 us).  Default (1): levels of 2^22 .. 2^26 cells; 3 = every
+    // level below 2^26; 2 = every level; 0 = never.
     bool zst = false;
     if constexpr (D == 3)
         zst = (ctx().opt[19] == 2 || (ctx().opt[19] == 3 && R.count() < (1L << 26)) || (ctx().opt[19] == 1 && R.count() < (1L << 26) && R.count() >= (1L << 22))) &&
               ctx().opt[5] != 0 && zrec && stencil7_ok<T>(p.g);
-    // No finalize launches (wl_set_option(15), default on; single rank, default kernel forms): the dot products z.eps and
-    // r.z' are finished by the NEXT kernel (every workgroup sums the <= 1024 partials and applies the scalar logic, Gate
-    // kind 1..3), the state travels through st->slots; only the last update keeps its finalize (it publishes the state).
-    // Levels above 2^25 cells keep the finalize launches (option 15 = 1; 2 = always): there the cap on the number of
-    // workgroups that keeps the in-kernel sums cheap costs the streaming kernels more than the launches it saves
-    // (512^3: +0.8 %; 256^3 and every coarser level: -2.8 %).
+    // ---- how the dot products are finished (PcgDots above).  The in-kernel sums want few partials: the kernels of such a
+    // call cut z into at most `zcap` chunks (Gate::zcap); levels above 2^25 cells keep the finalize launches (option 15 = 1;
+    // 2 = never): there the cap costs the streaming kernels more than the launches it saves (512^3: +0.8 %).
     const int tpp_v = D == 3 ? (((p.g.n[0] - 2 + 64 * VA::V - 1) / (64 * VA::V)) * ((p.g.n[1] - 2 + 3) / 4) + 7) / 8 * 8 : 0;
-    // z-slab levels (round 2): the same mechanism with the all-reduce in between -- the producer's partials are summed by
-    // k_reduce_only, all-reduced over the ranks, and the consuming kernel's gate applies the scalar logic to that ONE value
-    // (Gate kind 1..3 with np = 1): per dot product reduce + ncclAllReduce instead of reduce + ncclAllReduce + k_apply.
     const bool distr = p.g.dist && ctx().comm && ctx().comm->size > 1;
-    const bool infin = vec && xdef && zrec && R.count() > 0 && tpp_v > 0 &&
+    const bool gates = vec && xdef && zrec && R.count() > 0 && tpp_v > 0 &&
                        (distr ? ctx().opt[15] != 0
                               : ((ctx().opt[15] == 2 || (ctx().opt[15] == 1 && R.count() <= (1L << 25))) && tpp_v <= WL_PCG_PARTIALS));
-    // the in-kernel sums want few partials: the kernels of such a call cut z into at most `zcap` chunks (Gate::zcap)
-    const int zcap = (infin && !distr) ? std::max(WL_PCG_PARTIALS / std::max(tpp_v, 1), 1) : 0;
-    // what the consuming gate sums: the producer's partials, or (z-slabs) the one all-reduced value
-    auto ready = [&](const double *&part, int &n) -> int {
-        if (!distr) return 0;
-        Prof pr(WL_K_SCALAR, 0);
-        WL_TRY((reduce_allreduce<1>(part, n, (int)RED_SUM, 0.0, st->red)));
-        part = st->red;
-        n = 1;
-        return 0;
-    };
-    double *P0 = partials, *PA = infin ? partials + WL_MAXB : partials, *PB = infin ? partials + 2 * WL_MAXB : partials;
-    const int f32 = sizeof(T) == 4;
-    const int n0 = p.g.n[0];
-    int np0 = 0, npA = 0, cur = 0;   // cur: the slot holding the current state
-    // :125-127
+    const PcgForm form = !gates ? PcgForm::FINALIZE : (distr ? PcgForm::SLAB : PcgForm::IN_KERNEL);
+    const int zcap = form == PcgForm::IN_KERNEL ? std::max(WL_PCG_PARTIALS / std::max(tpp_v, 1), 1) : 0;
+    PcgDots<T> dots(form, st, partials, p.g.dist, xdef, want_r2, (T)10 * Lim<T>::eps, zcap);
+    const bool own = form != PcgForm::FINALIZE;   // the vector kernels must take the launch: the gates live in them
+    int np = 0, np0 = 0, npA = 0;
+
+    // ---- :125-127  eps = z = r*iD ; rho = r.z
     int rv0 = -1;
     if (pre_np >= 0) { rv0 = 0; np = np0 = pre_np; }
     else if (vec) {
-        Gate gate_init;
-        gate_init.zcap = zcap;
+        Gate gate_init = dots.base();
         rv0 = launch_rowvec<T, 1, true>(WL_K_PCG_INIT, p.g,
             [=] __device__(long o, int, int, const Pre &) { return VA::load(q.r + o); },
             [=] __device__(long o, int i, int, int, const VA &rr, const auto &rk, double *acc, const Pre &) {
@@ -1342,11 +1458,11 @@ _Pragma("unroll")
                 for (int v = 0; v < VA::V; ++v) { zv.v[v] = rr.v[v] * id.v[v]; acc[0] += (double)rr.v[v] * (double)zv.v[v]; }
                 if (!zrec) zv.store(q.z + o);
                 zv.store(q.eps + o);
-            }, p.rowc, P0, &np, gate_init);
+            }, p.rowc, dots.P0, &np, gate_init);
         if (rv0 > 0) return rv0;
         np0 = np;
     }
-    if (infin && rv0 != 0) return fail(WL_E_STATE, "pcg: vector init kernel rejected", __FILE__, __LINE__);
+    if (own && rv0 != 0) return fail(WL_E_STATE, "pcg: vector init kernel rejected", __FILE__, __LINE__);
     if (rv0 != 0)
     WL_TRY((launch_range_red<1>(WL_K_PCG_INIT, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
         const long I = q.g.at(i, j, k);
@@ -1355,41 +1471,28 @@ _Pragma("unroll")
         q.eps[I] = v;
         acc[0] += (double)q.r[I] * (double)v;
     }, partials, RED_SUM, 0.0, &np)));
-    if (!infin)
-    WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
-        const T rho = (T)v[0];
-        st->rho = (double)rho;
-        st->nupd = 0;
-        st->r2_valid = 0;
-        st->xpend = 0;
-        st->active = !((rho < 0 ? -rho : rho) < eps10);
-    })));
+    WL_TRY(dots.after_init(np));
+
     for (int n = 1; n <= it; ++n) {
-        WL_TRY((op_bc_per<T, D>(p.g, p.eps, permask, false)));  // :129 (x/y copies; the z-slab halo exchange follows)
+        const bool last = (n == it);
+        const bool xnow = last || !xdef;   // x += alpha*eps in the update kernel (else in the direction kernel)
+        // ---- :129-131  perBC!(eps) ; z = A eps ; z.eps
+        WL_TRY((op_bc_per<T, D>(p.g, p.eps, permask, false)));  // (x/y copies; the z-slab halo exchange follows)
         bool exchanged = false;
-        // :130-131
         int rcv = -1;
         if constexpr (D == 3) {
             if (stencil7_ok<T>(p.g)) {
                 exchanged = true;
                 Gate gate_mult;
-                if (!infin) gate_mult.active = &st->active;
-                else if (n == 1) {
-                    const double *gp = P0; int gn = np0;
-                    WL_TRY(ready(gp, gn));
-                    gate_mult.kind = 1; gate_mult.part = gp; gate_mult.np = gn; gate_mult.out = &st->slots[0]; cur = 0;
-                }
-                else { gate_mult.kind = 4; gate_mult.in = &st->slots[cur]; }
-                gate_mult.eps10 = (double)eps10; gate_mult.f32 = f32; gate_mult.zcap = zcap;
+                WL_TRY(dots.gate_mult(n, np0, gate_mult));
                 rcv = launch_stencil7_halo<T, 1>(WL_K_PCG_MULT, p.g, p.eps, SrcArray<T>{p.eps}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
                     [=] __device__(long o, int, int, int, const VA &ae, const VA &ec, const VA &, const VA &, const auto &, double *acc, const Pre &) {
                     if (!zst) ae.store(q.z + o);
 _Pragma("unroll")
                     for (int v = 0; v < VA::V; ++v) acc[0] += (double)ae.v[v] * (double)ec.v[v];
-                }, PA, &np, gate_mult);
+                }, dots.PA, &np, gate_mult);
                 if (rcv > 0) return rcv;
-                if (infin && rcv != 0) return fail(WL_E_STATE, "pcg: vector mult kernel rejected", __FILE__, __LINE__);
-                npA = np;
+                if (own && rcv != 0) return fail(WL_E_STATE, "pcg: vector mult kernel rejected", __FILE__, __LINE__);
             }
         }
         if (!exchanged) WL_TRY((halo_exchange<T>(p.g, p.eps, 1, 1)));
@@ -1408,35 +1511,19 @@ _Pragma("unroll")
             int planes = 0, nps = 0;
             for (int j = 0; j < D; ++j) if ((permask >> j) & 1) planes |= 3 << (2 * j);
             const G gg = p.g;
-            double *dst = (rcv == 0 ? PA : partials) + np;
             WL_TRY((launch_shell_red(WL_K_PCG_MULT, p.g, planes, [=] __device__(int i, int j, int k, double(&acc)[1]) {
                 const long I = gg.at(i, j, k);
                 acc[0] += (double)q.z[I] * (double)q.eps[I];
-            }, dst, RED_SUM, 0.0, &nps, infin ? 32 : 256)));
+            }, (rcv == 0 ? dots.PA : partials) + np, RED_SUM, 0.0, &nps, own ? 32 : 256)));
             np += nps;
-            if (rcv == 0) npA = np;
         }
-        if (!infin)
-        WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
-            st->xpend = 0;   // any owed x update was applied by the direction kernel before this mult
-            if (!st->active) return;
-            const T alpha = (T)st->rho / (T)v[0];
-            const double aa = (double)(alpha < 0 ? -alpha : alpha);
-            st->alpha = (double)alpha;
-            if (aa < 1e-2 || aa > 1e2) st->active = 0;  // :132
-        })));
-        const bool last = (n == it);
-        const bool xnow = last || !xdef;   // x += alpha*eps in the update kernel (else in the direction kernel)
-        // :133-137
+        npA = np;
+        WL_TRY(dots.after_mult(np));
+
+        // ---- :133-137  x += alpha eps (now or deferred) ; r -= alpha z ; z' = r*iD ; r.z'  (last iteration: r.r)
         int rvu = -1;
         Gate gate_upd;
-        if (!infin) { gate_upd.active = &st->active; gate_upd.s0 = &st->alpha; }
-        else {
-            const double *gp = PA; int gn = npA;
-            WL_TRY(ready(gp, gn));
-            gate_upd.kind = 2; gate_upd.part = gp; gate_upd.np = gn; gate_upd.in = &st->slots[cur]; gate_upd.out = &st->slots[cur ^ 1];
-        }
-        gate_upd.eps10 = (double)eps10; gate_upd.f32 = f32; gate_upd.zcap = zcap;
+        WL_TRY(dots.gate_update(npA, gate_upd));
         if constexpr (D == 3) {
             if (zst) {   // 7-point kernel over eps: Ae == the z the mult kernel would have stored; a = r, b = x (when x is due)
                 auto upd_epi = [=] __device__(long o, int i, int, int, const VA &ae, const VA &ec, const VA &r0, const VA &x0, const auto &rk, double *acc, const Pre &pre) {
@@ -1461,9 +1548,9 @@ _Pragma("unroll")
                     }
                 };
                 const T *xin = xnow ? (const T *)q.x : (const T *)nullptr;
-                rvu = launch_stencil7<T, 1>(WL_K_PCG_UPDATE, p.g, SrcArray<T>{p.eps}, p.L, p.rowc, (const T *)q.r, xin, upd_epi, PB, &np, gate_upd);
+                rvu = launch_stencil7<T, 1>(WL_K_PCG_UPDATE, p.g, SrcArray<T>{p.eps}, p.L, p.rowc, (const T *)q.r, xin, upd_epi, dots.PB, &np, gate_upd);
                 if (rvu != 0) return rvu > 0 ? rvu : fail(WL_E_STATE, "pcg: 7-point update kernel rejected", __FILE__, __LINE__);
-                if (infin) cur ^= 1;
+                dots.launched_update();
             }
         }
         if (vec && rvu != 0) {
@@ -1498,10 +1585,10 @@ _Pragma("unroll")
 _Pragma("unroll")
                         for (int v = 0; v < VA::V; ++v) acc[0] += (double)rr.v[v] * (double)rr.v[v];
                     }
-                }, p.rowc, PB, &np, gate_upd);
+                }, p.rowc, dots.PB, &np, gate_upd);
             if (rvu > 0) return rvu;
-            if (infin && rvu != 0) return fail(WL_E_STATE, "pcg: vector update kernel rejected", __FILE__, __LINE__);
-            if (infin) cur ^= 1;
+            if (own && rvu != 0) return fail(WL_E_STATE, "pcg: vector update kernel rejected", __FILE__, __LINE__);
+            if (rvu == 0) dots.launched_update();
         }
         if (rvu != 0)
         WL_TRY((launch_range_red<1>(WL_K_PCG_UPDATE, R, [=] __device__(int i, int j, int k, double(&acc)[1]) {
@@ -1519,47 +1606,13 @@ _Pragma("unroll")
                 acc[0] += (double)rn * (double)rn;
             }
         }, partials, RED_SUM, 0.0, &np)));
-        if (infin) {
-            if (last) {   // the one finalize of the call: finishes r.r (:135) and publishes the state for the host / L2
-                const int cs = cur;
-                WL_TRY((launch_finalize<1>(p.g.dist, PB, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
-                    PcgS sl = st->slots[cs];
-                    if (sl.active) {
-                        sl.nupd += 1;
-                        if (want_r2) { sl.r2 = (double)(T)v[0]; sl.r2_valid = 1; }
-                        sl.active = 0;
-                    }
-                    st->rho = sl.rho; st->alpha = sl.alpha; st->beta = sl.beta;
-                    st->active = sl.active; st->xpend = sl.xpend; st->nupd = sl.nupd;
-                    st->r2_valid = sl.r2_valid;
-                    if (sl.r2_valid) st->r2 = sl.r2;
-                })));
-            }
-        } else
-        WL_TRY((launch_finalize<1>(p.g.dist, partials, np, RED_SUM, 0.0, st->red, [=] __device__(const double *v) {
-            if (!st->active) return;
-            st->nupd += 1;
-            if (last) {  // :135
-                if (want_r2) { st->r2 = (double)(T)v[0]; st->r2_valid = 1; }
-                st->active = 0;
-                return;
-            }
-            const T rho2 = (T)v[0];
-            if ((rho2 < 0 ? -rho2 : rho2) < eps10) { st->active = 0; st->xpend = !xnow; return; }  // :138
-            st->beta = (double)(rho2 / (T)st->rho);
-            st->rho = (double)rho2;
-        })));
+        WL_TRY(dots.after_update(np, last, xnow));
         if (last) break;
-        // :140
+
+        // ---- :140  eps = beta eps + z'  (+ the deferred x += alpha eps)
         int rvd = -1;
         Gate gate_dir;
-        if (!infin) { gate_dir.active = &st->active; gate_dir.also = xdef ? &st->xpend : nullptr; gate_dir.s0 = &st->alpha; gate_dir.s1 = &st->beta; }
-        else {
-            const double *gp = PB; int gn = np;
-            WL_TRY(ready(gp, gn));
-            gate_dir.kind = 3; gate_dir.part = gp; gate_dir.np = gn; gate_dir.in = &st->slots[cur]; gate_dir.out = &st->slots[cur ^ 1]; gate_dir.also_x = 1;
-        }
-        gate_dir.eps10 = (double)eps10; gate_dir.f32 = f32; gate_dir.zcap = zcap;
+        WL_TRY(dots.gate_direction(np, gate_dir));
         if (vec) {
             struct DD { VA e, x, z; };
             rvd = launch_rowvec<T, 0, true>(WL_K_PCG_DIR, p.g,
@@ -1595,8 +1648,8 @@ _Pragma("unroll")
                     ev.store(q.eps + o);
                 }, p.rowc, nullptr, nullptr, gate_dir);
             if (rvd > 0) return rvd;
-            if (infin && rvd != 0) return fail(WL_E_STATE, "pcg: vector direction kernel rejected", __FILE__, __LINE__);
-            if (infin) cur ^= 1;
+            if (own && rvd != 0) return fail(WL_E_STATE, "pcg: vector direction kernel rejected", __FILE__, __LINE__);
+            if (rvd == 0) dots.launched_direction();
         }
         if (rvd != 0)
         WL_TRY(launch_range(WL_K_PCG_DIR, R, [=] __device__(int i, int j, int k) {
