@@ -257,7 +257,7 @@ def test_vtk_snapshot_every_step_at_512_costs_the_stepper_little(tmp_path):
     from waterlily_amd import vtk
     import bench
     sim = bench.sphere((512, 512, 512), np.float32)
-    for _ in range(3):
+    for _ in range(12):                     # past the start-up steps (2-3 V-cycles per solve): both timings in the steady state
         S.sim_step(sim, remeasure=False)
 
     def steps(n, each=None):
