@@ -298,7 +298,16 @@ def main(argv=None):
     T = np.float32 if args.dtype == "f32" else np.float64
     tsz = np.dtype(T).itemsize
     transport = "none" if world == 1 else {"rccl": "rccl", "host": "host-staging(gloo)", "loopback": "loopback(device copies, one process)"}[args.comm]
-    if args.comm in ("host", "loopback"):
+    if args.comm == "rccl" and os.environ.get("WL_RCCL_OVER_SOCKETS") == "1" and world > 1:
+        transport = "rccl(socket transport between ranks sharing one GPU: a test, not xGMI)"
+    # WL_RCCL_OVER_SOCKETS=1 (tests on a ONE-GPU box): the ranks share the device and present themselves to RCCL as different hosts,
+    # so the library's RCCL communicator pairs them over its socket transport -- every RCCL call of the run really executes between
+    # processes; torch's own process group (barriers, the max over the ranks) then runs on gloo.  Never an xGMI number.
+    sockets = real_rccl_sockets = (args.comm == "rccl" and os.environ.get("WL_RCCL_OVER_SOCKETS") == "1" and world > 1)
+    if sockets:
+        os.environ.update(NCCL_HOSTID=f"wl-bench-host-{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_P2P_DISABLE="1",
+                          NCCL_SHM_DISABLE="1", NCCL_NET_GDR_LEVEL="0")
+    if args.comm in ("host", "loopback") or sockets:
         local = local % max(1, torch.cuda.device_count())
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
@@ -307,7 +316,10 @@ def main(argv=None):
         # one process per GPU; the z axis is cut into `world` slabs, halos + scalar all-reduces run over RCCL (xGMI).
         # A communicator that cannot be created is a failed run (non-zero exit with the library's error text): a number
         # produced over any other transport would not be an xGMI measurement.
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if real_rccl_sockets:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
         try:
             wd.init_rccl()
         except Exception as e:
@@ -389,7 +401,7 @@ def main(argv=None):
     sync()
     elapsed = time.perf_counter() - t0
     if real:  # MAX over ranks
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.comm == "rccl" else "cpu")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if (args.comm == "rccl" and not real_rccl_sockets) else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     nl, nc, ms = C.c_int64(), C.c_int64(), C.c_double()

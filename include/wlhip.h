@@ -226,7 +226,8 @@ int wl_flow_update(wl_flow *a);
  * wl_mg_update (to which it falls back when the flow's last change was not a native measure!, or in 2-D).
  * Periodic y / z: the last interior row also follows the first one (its upper ghost row is that row's periodic copy); a
  * z-periodic ring of slabs takes the full update.  Consumes the flow's changed-row record: flags of several
- * wl_measure_fill calls accumulate until this call (or wl_mg_update_changed of the same flow) has used them. */
+ * wl_measure_fill calls accumulate until this call has used them -- so ONE hierarchy per flow may be updated this way (the
+ * reference builds exactly one, src/WaterLily.jl:77); a second hierarchy on the same mu0 must take wl_mg_update. */
 int wl_mg_update_changed(wl_mg *m, wl_flow *a);
 /* measure!(flow, body; t, eps)        src/Body.jl:31-53 for a PARAMETRIC body: an sdf family with closed-form gradient
  * (what ForwardDiff.gradient returns, src/AutoBody.jl:119) composed with an affine map xi = A x + b evaluated by the

@@ -87,10 +87,14 @@ def main():
             print("RESULT " + json.dumps(out), flush=True)
         dist.destroy_process_group()
         return
-    ref = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=None, **kw)
+    # "oblique": a stream with a large component along z leaves conv_diff!'s flux scratch ~ w^2 in sigma's ghost cells of the exit
+    # plane, above every interior flux_out: the whole-array maximum(a.sigma) of CFL (Flow.jl:174) is a GHOST cell, found by the
+    # shell reduction of whichever rank owns it
+    ubc = (0.5, 1.0, 4.0) if "oblique" in case else (1.0, 0.0, 0.0)
+    ref = S.Simulation(dims, ubc, L, slab=None, **kw)
     slab = wd.Slab(rank, size, dims[2], ring=(2 in perdir))
     # "deep": keep every level a slab as long as the partition allows; default: replicate levels <= 2^21 cells
-    sim = S.Simulation(dims, (1.0, 0.0, 0.0), L, slab=slab, replicate_cells=0 if "deep" in case else 1 << 21, **kw)
+    sim = S.Simulation(dims, ubc, L, slab=slab, replicate_cells=0 if "deep" in case else 1 << 21, **kw)
     out = {"rank": rank, "levels": [(tuple(l.layout.Ng), l.layout.slab is not None) for l in sim.pois.levels]}
     big = "big" in case
 
@@ -117,6 +121,8 @@ def main():
         S.sim_step(sim, remeasure="move" in case)
     out["n_ref"], out["n_slab"] = list(ref.pois.n), list(sim.pois.n)
     out["dt_ref"], out["dt_slab"] = list(ref.flow.dt), list(sim.flow.dt)
+    sg = S.to_host(ref.flow.sigma)
+    out["sigma_max_whole_over_inside"] = float(sg.max() / sg[S.inside(sg)].max())
     for k in ("u", "p", "f"):
         if big:
             out["d_" + k] = on_device(getattr(sim.flow, k), getattr(ref.flow, k), True)

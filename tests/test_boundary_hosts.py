@@ -96,16 +96,40 @@ def test_bench_launches_its_own_ranks():
 
 
 @pytest.mark.gpu
-def test_bench_loopback_rank_runs_the_slab_of_one_rank():
-    """bench.py --comm loopback: one process plays a rank of 8 (default: the second one, an interior slab the body does not
-    reach) -- its 1/8 slab with halos, split launches, reductions and (device-copy) exchanges; the solver converges as in a
-    real run and the collective counters are those of a real rank."""
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--comm", "loopback", "--grid", "64", "64", "128",
-                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=_env(), cwd=ROOT,
-                       timeout=900)
+def test_bench_rccl_path_between_two_processes():
+    """bench.py's PRODUCTION transport path (--comm rccl: ncclCommInitRank from a broadcast id, the mailbox, RCCL halo exchanges and
+    all-gathers, the communicator assertion, rank 0's one-GPU leg after the communicator is gone) between two real processes on the
+    one GPU of the box: they present themselves to RCCL as two hosts, so it pairs them over sockets (WL_RCCL_OVER_SOCKETS=1)."""
+    env = dict(_env(), WL_RCCL_OVER_SOCKETS="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--size", "64", "--steps", "2", "--warmup", "1", "--ref1-steps", "2"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
-    assert out["loopback"]["rank"] == 1 and out["loopback"]["of"] == 8 and out["config"]["comm_ranks"] == 8
-    assert max(out["config"]["vcycles_per_solve"]) <= 3
+    assert out["n_gpus"] == 2 and out["config"]["comm_ranks"] == 2 and out["config"]["transport"].startswith("rccl")
+    assert out["config"]["scalar_allreduce"].startswith("mailbox") and out["speedup_vs_1gpu"] > 0
     cl = out["config"]["collectives_last_step"]
-    assert cl["allreduce"] > 0 and cl["exchanges"] > 0 and cl["allgather"] > 0
+    assert cl["allreduce"] > 0 and cl["exchanges"] > 0 and max(out["config"]["vcycles_per_solve"]) <= 3
+
+
+@pytest.mark.gpu
+def test_bench_loopback_rank_runs_the_slab_of_one_rank():
+    """bench.py --comm loopback: one process plays a rank of an N-way split -- its slab with halos, split launches, reductions
+    and (device-copy) exchanges, the body shrunk to fit the slab.  Two ranks: the solver converges as in a real run and the
+    line carries the per-rank step time; eight ranks: the copy-of-itself neighbours do not fit the replicated coarse levels,
+    the solves stall, and the line SAYS so instead of quoting a step time (only its per-launch class times are usable)."""
+    def run(n):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--comm", "loopback", "--grid", "64", "64", "128",
+                            "--steps", "2", "--warmup", "4", "--no-cpu-baseline"], capture_output=True, text=True, env=_env(), cwd=ROOT,
+                           timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    out = run(2)
+    assert out["loopback"]["rank"] == 1 and out["loopback"]["of"] == 2 and out["config"]["comm_ranks"] == 2
+    assert out["loopback"]["solver_converged"] and out["loopback"]["per_rank_ms_per_step"] > 0
+    assert max(out["config"]["vcycles_per_solve"]) <= 4
+    cl = out["config"]["collectives_last_step"]
+    assert cl["allreduce"] > 0 and cl["exchanges"] > 0
+    out8 = run(8)
+    assert out8["loopback"]["of"] == 8 and out8["config"]["collectives_last_step"]["allgather"] > 0
+    if not out8["loopback"]["solver_converged"]:
+        assert out8["loopback"]["per_rank_ms_per_step"] is None and "STALLED" in out8["loopback"]["caveat"]

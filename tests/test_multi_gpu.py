@@ -158,7 +158,8 @@ def check(out, T):
                                         (2, "sphere_zper_deep_f32"), (4, "sphere_long_zper_deep_f64"),
                                         (2, "sphere_yzper_accel_deep_f64"), (2, "sphere_yper_exit_accel_f32"),
                                         (2, "sphere_move_deep_f32"), (4, "sphere_long_move_f64"),
-                                        (4, "sphere_vlong_deep_f32")])
+                                        (4, "sphere_vlong_deep_f32"),
+                                        (2, "sphere_oblique_deep_f32"), (4, "sphere_long_oblique_f64")])
 def test_slabs_match_undecomposed(nproc, case):
     out = run_workers("mg_worker.py", nproc, case)
     # "deep", 32^3 on 2 ranks: levels 32,16,8 (16,8,4 planes per rank) are slabs, 4^3 and 2^3 are replicated;
@@ -170,6 +171,8 @@ def test_slabs_match_undecomposed(nproc, case):
     if "vlong" in case:                   # 64x64x128 on 4 ranks: 32, 16, 8, 4, 2 planes per rank, then the hand-over to 4^3
         assert out["slab_nzl"] == [32, 16, 8, 4, 2, None]
     assert out["mailbox"]                 # scalars went through the mailbox all-reduce (the default once a communicator exists)
+    if "oblique" in case:                 # a ghost cell of sigma sets the time step: the slabs' shell reductions must find it
+        assert out["sigma_max_whole_over_inside"] > 1.5, out["sigma_max_whole_over_inside"]
     check(out, "f64" if case.endswith("f64") else "f32")
     check_collectives(out, exitBC="exit" in case)
 

@@ -371,9 +371,10 @@ template <class T, int D> static int mg_log_row(wl_mg *m, int n, bool have_r2) {
     m->log.push_back((double)n); m->log.push_back(m->sc.hst->out[1]); m->log.push_back(m->sc.hst->r2);
     return 0;
 }
-template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, int *n_iter, const T *divu = nullptr, const G *gu = nullptr) {
+template <class T, int D> static int mg_solve(wl_mg *m, double tol, int itmx, int *n_iter, const T *divu = nullptr, const G *gu = nullptr,
+                                              bool halo_begun = false) {
     LevelT<T> p = lvl<T>(m, 0);
-    WL_TRY((op_residual<T, D>(p, m->permask, m->sc.partials, m->sc.st, divu, gu)));
+    WL_TRY((op_residual<T, D>(p, m->permask, m->sc.partials, m->sc.st, divu, gu, halo_begun)));
     int n = 0;
     if (m->log_on) WL_TRY((mg_log_row<T, D>(m, 0, false)));
     while (n < itmx) {
@@ -410,8 +411,17 @@ template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double d
     const double dts = sc.s;
     const bool dbl = sc.dbl;
     const Range R = r_inside(g);
-    bool fused_div = false;
-    if (exchange_u && D == 3 && g.dist && overlap_on() && R.hi[2] - R.lo[2] + 1 >= 2) {
+    // 3-D vector kernels: z = div(u) is formed inside residual! (wl_set_option(22)); p.z stays unwritten
+    // (rowvec_fits: a plane's workgroups fit the partial buffer -- the launch below cannot be rejected for its size)
+    const bool fused_div = D == 3 && ctx().opt[22] && ctx().opt[5] && stencil7_ok<T>(g) && stencil7_ok<T>(p.g) && rowvec_fits<T>(p.g) && b->permask == 0 &&
+                           g.s[1] == p.g.s[1] && g.s[2] == p.g.s[2] && g.n[0] == p.g.n[0] && g.n[2] == p.g.n[2] && g.dist == p.g.dist;
+    bool begun = false;
+    if (fused_div && g.dist) {
+        // z-slabs: the plane of u that div reads above the last owned plane and the planes of x that residual! reads travel in ONE
+        // batch on the comm stream (x must carry its `.*= dt` first); the fused kernel runs on the inner planes meanwhile
+        if (!head_done) WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
+        if (exchange_u) { WL_TRY((halo_begin2<T>(g, (T *)a->d.u, D, 1, p.g, p.x, 1, 1))); begun = true; }
+    } else if (exchange_u && D == 3 && g.dist && overlap_on() && R.hi[2] - R.lo[2] + 1 >= 2) {
         WL_TRY((halo_begin<T>(g, (T *)a->d.u, D, 1)));
         int rc = head_done ? 0 : op_scale_all<T, D>(g, p.x, dts, false, dbl);
         if (!rc) rc = op_div<T, D>(g, p.z, (const T *)a->d.u, R.lo[2], R.hi[2] - 1);
@@ -420,14 +430,10 @@ template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double d
         WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u, R.hi[2], R.hi[2])));
     } else {
         if (exchange_u) WL_TRY((halo_exchange<T>(g, (T *)a->d.u, D, 1)));
-        // single device, 3-D vector kernels: z = div(u) is formed inside residual! (wl_set_option(22)); p.z stays unwritten
-        // (rowvec_fits: a plane's workgroups fit the partial buffer -- the launch below cannot be rejected for its size)
-        fused_div = D == 3 && !g.dist && ctx().opt[22] && ctx().opt[5] && stencil7_ok<T>(g) && stencil7_ok<T>(p.g) && rowvec_fits<T>(p.g) && b->permask == 0 &&
-                    g.s[1] == p.g.s[1] && g.s[2] == p.g.s[2] && g.n[0] == p.g.n[0];
         if (!fused_div) WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u)));
         if (!head_done) WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
     }
-    WL_TRY((mg_solve<T, D>(b, 1e-4, 32, n_iter, fused_div ? (const T *)a->d.u : nullptr, &g)));
+    WL_TRY((mg_solve<T, D>(b, 1e-4, 32, n_iter, fused_div ? (const T *)a->d.u : nullptr, &g, begun)));
     WL_TRY((op_correct<T, D>(g, (T *)a->d.u, p.L, p.x, p.rowc, xbc, xdone)));
     return op_scale_all<T, D>(g, p.x, dts, true, dbl, tail_then);
 }

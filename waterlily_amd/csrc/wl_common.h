@@ -636,6 +636,40 @@ template <class T> inline int halo_begin(const G &g, T *a, int ncomp, int depth)
     c.halo_pending = true;
     return 0;
 }
+// two arrays in ONE batch on the comm stream (project! on z-slabs: the planes of u that div reads and the planes of x that
+// residual! reads travel together: one latency, one event pair)
+template <class T> inline int halo_begin2(const G &ga, T *a, int ncompa, int deptha, const G &gb, T *b, int ncompb, int depthb) {
+    Ctx &c = ctx();
+    if (!ga.dist || !c.comm || c.comm->size == 1) return 0;
+    if (!overlap_on()) {
+        WL_TRY(c.comm->group_begin());
+        int rc = halo_exchange<T>(ga, a, ncompa, deptha);
+        if (!rc) rc = halo_exchange<T>(gb, b, ncompb, depthb);
+        const int rce = c.comm->group_end();
+        return rc ? rc : rce;
+    }
+    if (!c.cstream) {
+        WL_HIP(hipStreamCreateWithFlags(&c.cstream, hipStreamNonBlocking));
+        WL_HIP(hipEventCreateWithFlags(&c.ev_prod, hipEventDisableTiming));
+        WL_HIP(hipEventCreateWithFlags(&c.ev_halo, hipEventDisableTiming));
+    }
+    WL_HIP(hipEventRecord(c.ev_prod, c.stream));
+    WL_HIP(hipStreamWaitEvent(c.cstream, c.ev_prod, 0));
+    hipStream_t compute = c.stream;
+    c.stream = c.cstream;                       // the transport enqueues on ctx().stream
+    int rc = c.comm->group_begin();
+    if (!rc) {
+        rc = halo_exchange<T>(ga, a, ncompa, deptha);
+        if (!rc) rc = halo_exchange<T>(gb, b, ncompb, depthb);
+        const int rce = c.comm->group_end();
+        rc = rc ? rc : rce;
+    }
+    c.stream = compute;
+    if (rc) return rc;
+    WL_HIP(hipEventRecord(c.ev_halo, c.cstream));
+    c.halo_pending = true;
+    return 0;
+}
 inline int halo_end() {
     Ctx &c = ctx();
     if (!c.halo_pending) return 0;

@@ -1039,9 +1039,12 @@ _Pragma("unroll")
         rv.store(r + o);
     }
 };
-// divu / gu (optional, single device): take z = div(u) from the velocity field u laid out like the level (see above)
+// divu / gu (optional): take z = div(u) from the velocity field u laid out like the level (see above).  On a z-slab the kernel is
+// split like every 7-point launch (inner planes while x's halo planes travel, then the two boundary planes, whose upper one
+// also reads u's halo plane); begun: the caller has already started that exchange (flow_project sends u and x in one batch).
 template <class T, int D>
-int op_residual(const LevelT<T> &p, int permask, double *partials, State *st, const T *divu = nullptr, const G *gu = nullptr) {
+int op_residual(const LevelT<T> &p, int permask, double *partials, State *st, const T *divu = nullptr, const G *gu = nullptr,
+                bool begun = false) {
     WL_TRY((op_bc_per<T, D>(p.g, p.x, permask, false)));
     const LevelT<T> q = p;
     int np = 0;
@@ -1052,10 +1055,10 @@ int op_residual(const LevelT<T> &p, int permask, double *partials, State *st, co
             using VA = VecA<T>;
             exchanged = true;
             if (divu) {
-                if (p.g.dist || gu->s[1] != p.g.s[1] || gu->s[2] != p.g.s[2] || gu->n[0] != p.g.n[0])
+                if (gu->s[1] != p.g.s[1] || gu->s[2] != p.g.s[2] || gu->n[0] != p.g.n[0] || gu->n[2] != p.g.n[2])
                     return fail(WL_E_ARG, "residual with div(u): layouts differ", __FILE__, __LINE__);
-                rcv = launch_stencil7<T, 1>(WL_K_RESIDUAL, p.g, SrcArray<T>{p.x}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
-                                            ResidualDivEpi<T>{*gu, divu, q.iD, q.r, q.g.n[0]}, partials, &np);
+                rcv = launch_stencil7_halo<T, 1>(WL_K_RESIDUAL, p.g, p.x, SrcArray<T>{p.x}, p.L, p.rowc, (const T *)nullptr, (const T *)nullptr,
+                                                 ResidualDivEpi<T>{*gu, divu, q.iD, q.r, q.g.n[0]}, partials, &np, Gate(), begun);
                 if (rcv != 0) return rcv > 0 ? rcv : fail(WL_E_STATE, "residual with div(u): launch rejected", __FILE__, __LINE__);
             } else {
             rcv = launch_stencil7_halo<T, 1>(WL_K_RESIDUAL, p.g, p.x, SrcArray<T>{p.x}, p.L, p.rowc, (const T *)nullptr, p.z,

@@ -667,17 +667,20 @@ inline int launch_stencil7(int kclass, const G &g, SRC src, const T *L, const T 
 // not read a halo plane are computed WHILE the exchange is in flight; the first and last owned plane follow once it
 // has landed.  Reduction partials of the three launches are laid end to end (NRED <= 1).  Not decomposed / overlap
 // off / fewer than 3 planes: exchange in-stream, one launch.
+// begun (optional): the exchange this launch depends on was ALREADY started by the caller (halo_begin / halo_begin2, possibly
+// together with other arrays) -- it is only waited for here (hal is not exchanged again).
 template <class T, int NRED, class SRC, class EPI>
 inline int launch_stencil7_halo(int kclass, const G &g, T *hal, SRC src, const T *L, const T *rowc, const T *ea, const T *eb,
-                                EPI epi, double *partials, int *np, Gate gate = Gate()) {
+                                EPI epi, double *partials, int *np, Gate gate = Gate(), bool begun = false) {
     static_assert(NRED <= 1, "partials of the split launches are concatenated: one reduced value at most");
     const Range R = r_inside(g);
     const int lo = R.lo[2], hi = R.hi[2];
     if (!g.dist || !overlap_on() || hi - lo + 1 < 3) {
-        WL_TRY((halo_exchange<T>(g, hal, 1, 1)));
+        if (begun) WL_TRY(halo_end());           // (in-stream or already waited for: a no-op then)
+        else WL_TRY((halo_exchange<T>(g, hal, 1, 1)));
         return launch_stencil7<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials, np, gate);
     }
-    WL_TRY((halo_begin<T>(g, hal, 1, 1)));
+    if (!begun) WL_TRY((halo_begin<T>(g, hal, 1, 1)));
     ctx().n_overlapped += 1;
     int n1 = 0, n2 = 0, n3 = 0;
     int rc = launch_stencil7<T, NRED>(kclass, g, src, L, rowc, ea, eb, epi, partials, &n1, gate, lo + 1, hi - 1);
