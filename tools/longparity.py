@@ -4,7 +4,9 @@ remeasure=false): per step the V-cycle counts of both solves, the relative diffe
 max |dp| / max |p| and the pressure force of both.  The tests compare a handful of steps; this is the long horizon.
 (tools/ may use the oracle as a checker, like tests/: nothing here is product code.)
 
-usage: longparity.py <c1|c2|NxNxN|torus:N|moving:N> <f32|f64> <steps> [every] [self KEY A B]
+usage: longparity.py <c1|c2|NxNxN|torus:N|moving:N|pbox:N> <f32|f64> <steps> [every] [self KEY A B]
+  pbox:N = a sphere in a 2N x N x N box, periodic in y and z (round 4: the whole-array reductions of the reference -- sigma's
+  flux scratch in the ghost cells times eps's periodic copies -- on a long horizon)
   self KEY A B: instead of the oracle, a SECOND HIP simulation stepped with wl_set_option(KEY, B) next to the first with
   wl_set_option(KEY, A) -- e.g. `self 16 16 8` regroups the Float64 partial sums of every dot product (last-bit
   perturbations): how fast does the flow itself amplify rounding differences?"""
@@ -43,6 +45,13 @@ if case.startswith("torus:"):        # BASELINE C5's case at N^3: torus, Re = 10
     U = (1.0, 0.0, 0.0)
     so = O.Simulation(dims, U, Rm, nu=Rm / Re, body=G.Body(G.Torus(c, Rm, rm)), T=T)
     sh = S.Simulation(dims, U, Rm, nu=Rm / Re, body=B.Torus((c, c, c), Rm, rm), T=T)
+elif case.startswith("pbox:"):
+    m = int(case[5:]); dims = (2 * m, m, m); D = 3; Re = 1000.0
+    radius, center = m / 8, m / 2 - 1
+    U = (1.0, 0.0, 0.0)
+    kwp = dict(nu=2 * radius / Re, perdir=(1, 2), T=T)
+    so = O.Simulation(dims, U, 2 * radius, body=G.Body(G.Sphere(center, radius)), **kwp)
+    sh = S.Simulation(dims, U, 2 * radius, body=B.Sphere((center,) * 3, radius, 3), **kwp)
 elif case.startswith("moving:"):     # a circle accelerating through fluid at rest, measure! + update! every step (maintests.jl:391-412 family)
     m = int(case[7:]); dims = (2 * m, m); D = 2; Re = 250.0; remeasure = True
     radius = m / 8
