@@ -370,18 +370,19 @@ function measure!(sim::Simulation, t=sum(sim.flow.Δt))
 end
 # nds band of a parametric body (Metrics.jl:84-87): wl_body_nds on the band cells measure! listed; returns element offsets + vectors
 function band(p::HIPArray, body::ParametricBody, t)
-    D = ndims(p)
-    cells = Int64[LinearIndices(size(p))[I] - 1 for I ∈ inside(p)]     # (a maintainer would keep BAND[flow][2]: the |d|<2+ϵ cells)
-    cand = HIPArray(cells); v = HIPArray{Float64,1}((D * length(cells),))
+    D = ndims(p); Is = collect(inside(p))
+    cells = Int64[LinearIndices(size(p))[I] - 1 for I ∈ Is]            # dense cell indices i + n₀(j + n₁k): what wl_body_nds takes
+    offs = Int64[offset(p, Tuple(I)...) for I ∈ Is]                    # element offsets in the PITCHED field: what wl_pforce takes
+    cand = HIPArray(cells); v = HIPArray{Float64,1}((D * length(cells),))   # (a maintainer would keep BAND[flow][2]: the |d|<2+ϵ cells)
     chk(ccall((:wl_body_nds, lib), Cint, (Ref{WlGrid}, Ref{WlBody}, Ptr{Int64}, Int64, Ptr{Cdouble}), grid(p), desc(body, t, D),
               cand.ptr, length(cells), v.ptr))
-    cand, v            # dense layout: the local column-major index IS the element offset wl_pforce expects
+    HIPArray(offs), v
 end
 function band(p::HIPArray, body, t)                                                             # Metrics.jl:84-87 on the |d|<=1 band
     T = promote_type(Float64, eltype(p)); idx = Int64[]; v = Float64[]
     for I ∈ inside(p)
         n = nds(body, loc(0, I, T), t)
-        any(!iszero, n) && (push!(idx, LinearIndices(size(p))[I] - 1); append!(v, n))
+        any(!iszero, n) && (push!(idx, offset(p, Tuple(I)...)); append!(v, n))   # element offset in the pitched field
     end
     HIPArray(idx), HIPArray(v)
 end

@@ -254,7 +254,7 @@ def write(w: VTKWriter, sim) -> None:
         _lib.check(L.wl_snapshot_pack(S._WLT[T], C.byref(g), C.c_void_p(a.data_ptr()), nc, nct, klo if D == 3 else 0,
                                       klo + npl - 1 if D == 3 else 0, C.c_void_p(slot.buf.data_ptr() + off)))
     ev = torch.cuda.Event()
-    ev.record()                                               # on the stream the library works on (the current one)
+    ev.record(torch.cuda.default_stream(flow.device))         # the stream the library works on (its default: the device's null stream)
     # file names and XML of this snapshot (no data yet)
     sl = sim.slab
     multi = sl is not None and sl.size > 1
