@@ -2,7 +2,7 @@
 """HIP path and CPU oracle side by side over MANY steps of a BASELINE configuration (README circle / sphere case,
 remeasure=false): per step the V-cycle counts of both solves, the relative difference of the time step, max |du| / U,
 max |dp| / max |p| and the pressure force of both.  The tests compare a handful of steps; this is the long horizon.
-(tools/ may use the oracle as a checker, like tests/: nothing here is product code.)
+(Lives under tests/: it uses the oracle as the checker; nothing here is product code.)
 
 usage: longparity.py <c1|c2|NxNxN|torus:N|moving:N|pbox:N> <f32|f64> <steps> [every] [self KEY A B]
   pbox:N = a sphere in a 2N x N x N box, periodic in y and z (round 4: the whole-array reductions of the reference -- sigma's
@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import geometry as G  # noqa: E402
 from oracle import wl_oracle as O  # noqa: E402
 from waterlily_amd import body as B  # noqa: E402

@@ -567,7 +567,7 @@ def test_c3_full_size_512_f32_against_the_oracle():
 
 def test_c2_full_size_256_f32_twelve_steps_against_the_oracle():
     """BASELINE config C2 itself (256^3 Float32 sphere, Re=3700; the CPU-baseline case of bench.py) over twelve steps:
-    identical V-cycle counts in every solve, time steps, u, p and the pressure force.  (tools/longparity.py runs the same pair
+    identical V-cycle counts in every solve, time steps, u, p and the pressure force.  (tests/checks/longparity.py runs the same pair
     for 60 steps: bitwise equal fields throughout, profiles/r03c_longparity_c2_256_f32_60steps.txt.)"""
     m = 256
     R, c = m / 8, m / 2 - 1
