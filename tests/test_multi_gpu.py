@@ -218,6 +218,21 @@ def test_rccl_two_ranks_on_one_gpu_over_sockets(mailbox):
 
 
 @pytest.mark.gpu
+def test_rccl_four_ranks_on_one_gpu_over_sockets():
+    """The same with FOUR ranks (32 x 32 x 64, slab levels of 16, 8, 4 and 2 planes per rank): the two middle ranks exchange with a
+    neighbour on either side inside one RCCL group, the all-gather collects four segments, the mailbox polls four slots --
+    the RCCL call pattern of an interior rank of the 8-GPU runs, between real processes."""
+    out = run_workers("mg_worker.py", 4, "sphere_long_rcclnet_deep_f32", timeout=400, allow_fail=True, NCCL_DEBUG="WARN")
+    if out.get("failed"):
+        if "RESULT" not in out["tail"] and ("rccl" in out["tail"].lower() or "nccl" in out["tail"].lower()):
+            pytest.skip("RCCL could not create a 4-rank communicator on one GPU: " + out["tail"][-600:])
+        raise AssertionError(out["tail"])
+    assert out["overlapped"] > 0 and out["mailbox"] and out["slab_nzl"][:4] == [16, 8, 4, 2]
+    check(out, "f32")
+    check_collectives(out)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nproc,case", [(2, "sphere_deep_f32"), (4, "sphere_long_zper_deep_f64")])
 def test_slabs_match_without_overlap(nproc, case):
     """Same, with the halo exchanges issued in-stream (WL_OVERLAP=0) instead of on the comm stream with the stencil
