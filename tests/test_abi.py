@@ -83,3 +83,24 @@ def test_no_gpu_fails_loudly():
     from waterlily_amd import sim
     with pytest.raises(_lib.WlError, match="no CPU fallback"):
         sim.Flow((16, 16), (1.0, 0.0))
+
+
+def test_abi_v6_entry_points_validate_without_gpu():
+    """ABI v6 additions reject bad calls before touching the device: pitched copies whose row is wider than a pitch, snapshot
+    staging with a bad tuple / plane range, the loopback communicator's rank, option queries of retired keys."""
+    L = _lib.lib()
+    assert L.wl_h2d_2d(None, 8, None, 16, 32, 1) == _lib.WL_E_ARG and b"wider than a pitch" in L.wl_last_error()
+    assert L.wl_d2h_2d(None, 64, None, 16, 32, 1) == _lib.WL_E_ARG
+    g = _lib.Grid()
+    g.D = 3
+    g.n[:] = [8, 8, 8]
+    g.s[:] = [1, 8, 64]
+    g.sc = 512
+    buf = (C.c_float * 4)()
+    assert L.wl_snapshot_pack(_lib.WL_F32, C.byref(g), buf, 3, 2, 0, 7, buf) == _lib.WL_E_ARG and b"ntuple" in L.wl_last_error()
+    assert L.wl_snapshot_pack(_lib.WL_F32, C.byref(g), buf, 3, 3, 2, 9, buf) == _lib.WL_E_ARG and b"plane range" in L.wl_last_error()
+    assert L.wl_snapshot_unpack(_lib.WL_F32, C.byref(g), None, 1, 1, 0, 0, buf) == _lib.WL_E_ARG
+    assert L.wl_comm_init_loopback(3, 2) == _lib.WL_E_ARG
+    n, b = C.c_int64(-1), C.c_int64(-1)
+    assert L.wl_prof_allocs(C.byref(n), C.byref(b)) == 0 and n.value >= 0 and b.value >= 0
+    assert L.wl_prof_allocs(None, None) == _lib.WL_E_ARG
