@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- MLUPS (cell-updates/s) per `sim_step!` of the 3-D sphere case (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
 One "step" = one `sim_step!(sim; remeasure=false)` = one `mom_step!` (predictor + corrector, both pressure
 solves, CFL).  Workload at N=1: BASELINE.json configs[2] (C3), the configuration the metric is quoted on:
 3-D sphere, 512^3, Float32, Re=3700, uniform inflow (geometry as README.md:118-125 of the reference).
+Workload at N>1: BASELINE.json configs[3] (C4), 1024 x 1024 x 512 Float32, cut into N z-slabs (one process per GPU, RCCL):
+STRONG scaling -- the north star's ">= 6x at 8 GPUs vs 1 GPU" case; `--weak` / `--size` / `--grid` choose other grids.
+Started by a launcher (`python -m torch.distributed.run ... bench.py --gpus N`, WORLD_SIZE set) the process is one rank; started
+bare with N > 1 it launches its N ranks itself as children (before importing torch: the parent never touches a GPU), relays
+rank 0's line and exits with their status.
 Inputs are synthetic and resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
 
 JSON extras:
@@ -19,7 +24,12 @@ JSON extras:
   smoother      the same three figures for the V-cycle smoother Jacobi!+increment! (the north-star's >=40 % kernel) and
   prolong_increment   for the fused prolongate!+increment! kernel, each on its own (finest level only)
   cpu_baseline  the CPU restatement of the reference (oracle/, OpenMP) on BASELINE.md section 3's two CPU points:
-                C2 256^3 Float32 sphere (`value`) and C1 2-D circle 192x64 Float64 (`c1`)
+                C2 256^3 Float32 sphere (`value`) and C1 2-D circle 192x64 Float64 (`c1`)  (N=1 only)
+  layout_dense  N=1: the same case once more in the reference's dense strides (pitch N+2: what a binding that hands over
+                Julia's own arrays would give), 5 steps in the steady state -- the headline runs on pitched rows, which is
+                what the reference-side binding allocates
+  one_gpu, speedup_vs_1gpu   N>1, strong scaling: the same global grid on ONE GPU (rank 0's, after the N-GPU run, same build)
+  loopback      --comm loopback: one process plays one rank of an N-way split (measurement tool)
 """
 from __future__ import annotations
 
