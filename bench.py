@@ -173,6 +173,15 @@ def cpu_baseline(size: int, steps: int, c1_steps: int):
                              f"remeasure=false, V-cycles/step={n1}"}}
 
 
+def _csrc_digest():
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import parse_pmc
+        return parse_pmc.csrc_digest()
+    except Exception:
+        return None
+
+
 def class_table(L):
     names = {}
     k = 0
@@ -453,6 +462,7 @@ def main(argv=None):
             rec["traffic_GB/s"] = rec["traffic"] / (avg_ms * 1e-3) / 1e9
             # a committed constant of an earlier rocprofv3 --pmc run of this command (tools/profile.sh), not measured by THIS run
             rec["traffic_source"] = "profiles/" + str(traffic_db.get("_source", {}).get(tkey, "?")) + "_pmc_traffic_*"
+            rec["traffic_build_matches"] = traffic_db.get("_csrc_sha1", {}).get(tkey) == _csrc_digest()   # same kernel sources as profiled?
         return rec
 
     roof = kernel_record(dominant, nl.value, nc.value, ms.value)

@@ -82,6 +82,19 @@ def collect(path, counter):
     return out, info
 
 
+def csrc_digest():
+    """sha1 over the kernel sources (waterlily_amd/csrc/*, include/wlhip.h): identifies the build a profile was taken on"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha1()
+    d = os.path.join(root, "waterlily_amd", "csrc")
+    for f in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "wlhip.h")]:
+        p = os.path.join(d, f)
+        if os.path.isfile(p):
+            h.update(f.encode() + b"\0" + open(p, "rb").read())
+    return h.hexdigest()
+
+
 def main():
     fpath, wpath, tag = sys.argv[1:4]
     source = sys.argv[4] if len(sys.argv) > 4 else None
@@ -102,6 +115,11 @@ def main():
         src = data.get("_source", {})
         src[tag] = source
         data["_source"] = src
+        # ... and of which kernel sources: bench.py compares this digest with the tree it runs from and says when the
+        # constants were measured on another build (`traffic_build_matches`)
+        dig = data.get("_csrc_sha1", {})
+        dig[tag] = csrc_digest()
+        data["_csrc_sha1"] = dig
     json.dump(data, open(tfile, "w"), indent=1, sort_keys=True)
 
 
