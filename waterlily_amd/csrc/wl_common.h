@@ -616,10 +616,20 @@ inline bool overlap_on() {
     }
     return c.overlap == 1 && c.comm && c.comm->size > 1;
 }
-template <class T> inline int halo_begin(const G &g, T *a, int ncomp, int depth) {
+// b (optional): a second array in the SAME batch (project! on z-slabs: the plane of u that div reads and the planes of x that
+// residual! reads travel together: one latency, one event pair)
+template <class T> inline int halo_begin2(const G &ga, T *a, int ncompa, int deptha, const G &gb, T *b, int ncompb, int depthb) {
     Ctx &c = ctx();
-    if (!g.dist || !c.comm || c.comm->size == 1) return 0;
-    if (!overlap_on()) return halo_exchange<T>(g, a, ncomp, depth);
+    if (!ga.dist || !c.comm || c.comm->size == 1) return 0;
+    auto both = [&]() -> int {                  // one group: one exchange batch
+        int rc = c.comm->group_begin();
+        if (rc) return rc;
+        rc = halo_exchange<T>(ga, a, ncompa, deptha);
+        if (!rc && b) rc = halo_exchange<T>(gb, b, ncompb, depthb);
+        const int rce = c.comm->group_end();
+        return rc ? rc : rce;
+    };
+    if (!overlap_on()) return both();
     if (!c.cstream) {
         WL_HIP(hipStreamCreateWithFlags(&c.cstream, hipStreamNonBlocking));
         WL_HIP(hipEventCreateWithFlags(&c.ev_prod, hipEventDisableTiming));
@@ -629,46 +639,15 @@ template <class T> inline int halo_begin(const G &g, T *a, int ncomp, int depth)
     WL_HIP(hipStreamWaitEvent(c.cstream, c.ev_prod, 0));
     hipStream_t compute = c.stream;
     c.stream = c.cstream;                       // the transport enqueues on ctx().stream
-    const int rc = halo_exchange<T>(g, a, ncomp, depth);
+    const int rc = both();
     c.stream = compute;
     if (rc) return rc;
     WL_HIP(hipEventRecord(c.ev_halo, c.cstream));
     c.halo_pending = true;
     return 0;
 }
-// two arrays in ONE batch on the comm stream (project! on z-slabs: the planes of u that div reads and the planes of x that
-// residual! reads travel together: one latency, one event pair)
-template <class T> inline int halo_begin2(const G &ga, T *a, int ncompa, int deptha, const G &gb, T *b, int ncompb, int depthb) {
-    Ctx &c = ctx();
-    if (!ga.dist || !c.comm || c.comm->size == 1) return 0;
-    if (!overlap_on()) {
-        WL_TRY(c.comm->group_begin());
-        int rc = halo_exchange<T>(ga, a, ncompa, deptha);
-        if (!rc) rc = halo_exchange<T>(gb, b, ncompb, depthb);
-        const int rce = c.comm->group_end();
-        return rc ? rc : rce;
-    }
-    if (!c.cstream) {
-        WL_HIP(hipStreamCreateWithFlags(&c.cstream, hipStreamNonBlocking));
-        WL_HIP(hipEventCreateWithFlags(&c.ev_prod, hipEventDisableTiming));
-        WL_HIP(hipEventCreateWithFlags(&c.ev_halo, hipEventDisableTiming));
-    }
-    WL_HIP(hipEventRecord(c.ev_prod, c.stream));
-    WL_HIP(hipStreamWaitEvent(c.cstream, c.ev_prod, 0));
-    hipStream_t compute = c.stream;
-    c.stream = c.cstream;                       // the transport enqueues on ctx().stream
-    int rc = c.comm->group_begin();
-    if (!rc) {
-        rc = halo_exchange<T>(ga, a, ncompa, deptha);
-        if (!rc) rc = halo_exchange<T>(gb, b, ncompb, depthb);
-        const int rce = c.comm->group_end();
-        rc = rc ? rc : rce;
-    }
-    c.stream = compute;
-    if (rc) return rc;
-    WL_HIP(hipEventRecord(c.ev_halo, c.cstream));
-    c.halo_pending = true;
-    return 0;
+template <class T> inline int halo_begin(const G &g, T *a, int ncomp, int depth) {
+    return halo_begin2<T>(g, a, ncomp, depth, g, (T *)nullptr, 0, 0);
 }
 inline int halo_end() {
     Ctx &c = ctx();
