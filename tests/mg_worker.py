@@ -44,7 +44,7 @@ def main():
         wd.init_host()
     rank, size = dist.get_rank(), dist.get_world_size()
     T = np.float64 if case.endswith("f64") else np.float32
-    m = 512 if "big" in case else 32
+    m = 512 if "big" in case else (40 if "five" in case else 32)     # (40 = 5 * 2^3: five slabs of 8, 4, 2 planes)
     dims = (m, m, m) if "long" not in case else ((2 * m, 2 * m, 4 * m) if "vlong" in case else (m, m, 2 * m))
     R, c = m / 8, m / 2 - 1
     if case.startswith("donut"):
