@@ -555,14 +555,15 @@ def test_sphere_96_f32(geometry):
 
 @pytest.mark.skipif(os.environ.get("WL_SKIP_512") == "1", reason="WL_SKIP_512=1")
 def test_c3_full_size_512_f32_against_the_oracle():
-    """BASELINE config C3 itself -- the 512^3 Float32 sphere the bench line is quoted on -- stepped twice by the CPU oracle
-    (about a minute on the box's 16 cores) and by the HIP path: identical V-cycle counts, dt within 1e-4, u within 5e-4
-    and p within 5e-3 of their maxima.  The size-independent properties of tests/test_fullsize_properties.py hold the
+    """BASELINE config C3 itself -- the 512^3 Float32 sphere the bench line is quoted on -- stepped by the CPU oracle (half a
+    minute per step on the box's 16 cores: ONE full step here -- predictor, corrector, both solves, CFL; rounds 2-3 ran two, the
+    twelve steps of C2 below and the 60-step record of tests/checks/longparity.py cover the sequence) and by the HIP path:
+    identical V-cycle counts, dt within 1e-4, u within 5e-4 and p within 5e-3 of their maxima.  The size-independent properties of tests/test_fullsize_properties.py hold the
     kernels to account at this size bit for bit; this is the direct comparison."""
     m = 512
     R, c = m / 8, m / 2 - 1
     so, sh = pair((m, m, m), (1.0, 0.0, 0.0), 2 * R, nu=2 * R / 3700, body=bodies.sphere(c, R), T=np.float32, geometry="device")
-    check_step(so, sh, np.float32, 2)
+    check_step(so, sh, np.float32, 1)
 
 
 def test_c2_full_size_256_f32_twelve_steps_against_the_oracle():

@@ -296,11 +296,11 @@ def test_bench_multirank_path():
     tests/test_boundary_hosts.py::test_bench_launches_its_own_ranks)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "host", "--size", "64",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "host", "--size", "32",
            "--weak", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert "64x64x128" in out["config"]["workload"]
+    assert "32x32x64" in out["config"]["workload"]
