@@ -270,7 +270,12 @@ int wl_body_nds(const wl_grid *g, const wl_body_desc *body, const int64_t *cand_
 int wl_project(wl_flow *a, wl_mg *b, double dt, double w, int *n_iter);
 /* mom_step!(a,b)                      src/Flow.jl:153-169.  dt = a.dt[end]; U = BCTuple(a.U,a.dt,N);
  * acc_pred/acc_corr = g(i,t)+dU_i/dt at t=sum(dt[1:end-1]) and t=sum(dt) (NULL when accelerate! is a
- * no-op, :73).  dt_next receives CFL(a); n_iter[2] the two entries pushed onto pois.n. */
+ * no-op, :73).  dt_next receives CFL(a); n_iter[2] the two entries pushed onto pois.n.
+ * The u0 ARRAY is scratch across the call, as in the reference (it is overwritten by `a.u⁰ .= a.u` before anything reads
+ * it, :154): on return it holds either the velocity the step started from (the reference's copy) or -- 3-D, no periodic
+ * direction, no convective exit, wl_set_option(27) -- the predictor's velocity u', because there the two velocity arrays
+ * take turns instead of being copied (the predictor reads u and writes u' into u0, the corrector writes the new velocity
+ * back into u).  u, p, f, sigma, the time step and the V-cycle counts are the same bits either way. */
 int wl_mom_step(wl_flow *a, wl_mg *b, double dt, const double U[3], const double *acc_pred,
                 const double *acc_corr, double *dt_next, int n_iter[2]);
 
@@ -350,6 +355,10 @@ int wl_snapshot_unpack(wl_dtype t, const wl_grid *g, void *a, int ncomp, int ntu
  *         follows covers the y and z planes only (default), 0 = BC! writes all six planes
  * key 26: bound of a mailbox all-reduce's wait for a peer in SECONDS of the device's wall clock (default 600; 0 = unbounded,
  *         like a collective)
+ * key 27: 1 = inside wl_mom_step (3-D, no periodic direction, no convective exit) the conv_diff! kernels finish BDIM!
+ *         (Flow.jl:134, scale_u! :166) on the body-free x-rows themselves: the row's new velocity is stored from the registers
+ *         that hold f, V is not read there, and no separate pass over those rows runs (6T + 9T per cell and step less);
+ *         the u0 array holds u' on return (see wl_mom_step) (default), 0 = separate BDIM! pass, u0 = the copy of u
  * key 30: 1 = consecutive marching kernels sweep their tiles in opposite directions, each XCD starting on the lines the
  *         kernel before it touched last (L2 / Infinity Cache) (default), 0 = always ascending.  Same bits either way.
  * key 31: 1 = inside the one-workgroup bottom of the V-cycle (levels of <= 4096 cells) pcg! keeps its level in registers and

@@ -54,7 +54,7 @@ def test_new_entry_points_validate_without_gpu():
     assert L.wl_mg_log(None, 1) != 0 and L.wl_mg_log_read(None, None, 0, None) != 0
     assert L.wl_mg_Linf(None, 0, None) != 0
     assert L.wl_set_option(31, 0) == 0 and L.wl_set_option(31, 1) == 0 and L.wl_set_option(32, 0) != 0
-    for retired in (11, 12, 20, 21, 24, 25, 27, 28, 29):       # round 4: keys whose alternative was a recorded loss are gone
+    for retired in (11, 12, 20, 21, 24, 25, 28, 29):       # round 4: keys whose alternative was a recorded loss are gone
         assert L.wl_set_option(retired, 1) == _lib.WL_E_ARG and b"no such option" in L.wl_last_error()
     v = C.c_int()
     assert L.wl_get_option(26, C.byref(v)) == 0 and v.value == 600 and L.wl_get_option(24, C.byref(v)) == _lib.WL_E_ARG

@@ -502,6 +502,55 @@ def test_project_div_inside_residual_bit_exact(T):
 
 
 @pytest.mark.parametrize("T", TYPES)
+@pytest.mark.parametrize("case", ["sphere", "sphere-on-the-wall", "moving", "gravity", "dense"])
+def test_bdim_finished_inside_conv_diff_bit_exact(T, case):
+    """wl_set_option(27): inside mom_step! the conv_diff! kernels finish BDIM! (Flow.jl:134, scale_u! :166) on the body-free
+    x-rows themselves -- the new velocity of such a row is stored from the registers that hold f, V is not read there, the
+    row's x-ghost cells of the following BC! are written too -- and the two velocity arrays take turns (the predictor writes
+    u' into the u0 array, the corrector the new velocity back into u), the busy rows keep their own kernel.  Same expressions
+    in the same order => u (ghost cells included), p, f, the time steps and the V-cycle counts after several steps are
+    bit-identical to the run with the separate BDIM! pass, which matches the oracle.  Cases: several x tiles per row; a body
+    cut by the domain wall (busy rows in the shell kernel's tile rows and planes); a moving body (V != 0 in the busy rows);
+    a body force (accelerate!); the reference's dense strides."""
+    dims = (136, 40, 24) if case != "dense" else (48, 40, 24)
+    R, c = dims[1] / 8, dims[1] / 2 - 1
+    kw = dict(T=T)
+    body = bodies.sphere(c, R)
+    if case == "sphere-on-the-wall":
+        body = bodies.sphere((c, 1.5, dims[2] - 2.5), R)
+    elif case == "moving":
+        body = bodies.moving_circle(dims[2] / 2 - 1.0, R, v=0.4, D=3)
+    elif case == "gravity":
+        kw["g"] = lambda i, t: 0.05 * (i + 1) * (1 + t)
+    elif case == "dense":
+        kw["padded"] = False
+    runs = []
+    for fused in (1, 0):
+        S.set_option(27, fused)
+        try:
+            so, sh = pair(dims, (1.0, 0.0, 0.0), 2 * R, nu=2 * R / 1000, body=body, **kw)
+            u_start = S.to_host(sh.flow.u).copy()
+            for _ in range(3):
+                u_before = S.to_host(sh.flow.u).copy()
+                S.sim_step(sh, remeasure=(case == "moving"))
+            runs.append((sh.pois.n[:], list(sh.flow.dt), S.to_host(sh.flow.u).copy(), S.to_host(sh.flow.p).copy(), S.to_host(sh.flow.f).copy(),
+                         S.to_host(sh.flow.u0).copy(), u_before))
+        finally:
+            S.set_option(27, 1)
+    a, b = runs
+    assert a[0] == b[0] and a[1] == b[1]
+    for q in (2, 3, 4):
+        assert np.array_equal(a[q], b[q]), q
+    # the one visible difference (DESIGN.md section 7): the u0 ARRAY.  Separate pass: the velocity the step started from
+    # (Flow.jl:154); fused: the predictor's velocity u' -- the reference overwrites u0 before it ever reads it
+    assert np.array_equal(b[5], b[6]) and not np.array_equal(a[5], a[6])
+    for _ in range(3):
+        O.sim_step(so, remeasure=(case == "moving"))
+    assert so.pois.n == a[0]
+    assert np.max(np.abs(a[2].astype(np.float64) - so.flow.u)) <= rtol(T) * 50 * float(np.max(np.abs(so.flow.u)))
+
+
+@pytest.mark.parametrize("T", TYPES)
 @pytest.mark.parametrize("exitBC", [False, True])
 def test_x_ghost_cells_written_by_the_producer_bit_exact(T, exitBC):
     """wl_set_option(23): inside mom_step! the x-ghost cells of the interior rows that BC!(u,U) sets are written by the
@@ -611,10 +660,10 @@ def test_bench_moving_cylinder_case_against_the_oracle(T):
     same(sh.flow.p, so.flow.p, exact=False, tol=rtol(T) * 500)
 
 
-SWITCHES = {0: 0, 1: 0, 2: 0, 3: 0, 5: 0, 6: 0, 7: 0, 8: 0, 9: 0, 10: 0, 13: 0, 14: 0, 15: 0, 18: 0, 19: 0, 22: 0, 23: 0, 30: 0, 31: 0}
+SWITCHES = {0: 0, 1: 0, 2: 0, 3: 0, 5: 0, 6: 0, 7: 0, 8: 0, 9: 0, 10: 0, 13: 0, 14: 0, 15: 0, 18: 0, 19: 0, 22: 0, 23: 0, 27: 0, 30: 0, 31: 0}
 
 
-@pytest.mark.parametrize("group", ["all-at-once", "vector-kernels-kept", "two-rows-and-no-finalize-launches"])
+@pytest.mark.parametrize("group", ["all-at-once", "vector-kernels-kept", "two-rows-and-no-finalize-launches", "x-planes-by-the-BC-launch"])
 def test_every_switch_flipped_at_once_changes_no_bit(group):
     """Every wl_set_option key that selects between the reference's form of an operator and a traffic-saving form of it, flipped
     TOGETHER (round 3 tested them one at a time): the default path and the all-reference-forms path -- generic range kernels,
@@ -637,6 +686,8 @@ def test_every_switch_flipped_at_once_changes_no_bit(group):
             flips.pop(k)
     elif group == "two-rows-and-no-finalize-launches":
         flips = {4: 2, 15: 2, 19: 2, 30: 0, 3: 0, 9: 0}
+    elif group == "x-planes-by-the-BC-launch":       # BDIM! still finished inside conv_diff!, the x-ghost cells by BC!'s own launch
+        flips = {23: 0}
     keep = {k: S.get_option(k) for k in flips}
     try:
         for k, v in flips.items():

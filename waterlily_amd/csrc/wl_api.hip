@@ -402,10 +402,12 @@ template <class T> static ScaleOp project_scale(double dt_, double w) {
     const bool dbl = (w != 1.0);
     return ScaleOp{dbl ? w * (double)(T)dt_ : (double)(T)dt_, false, dbl};
 }
+// uvel: the velocity array to project (mom_step! may hold the predicted velocity in the flow's u0 array; default a->d.u)
 template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double dt_, double w, int *n_iter, bool exchange_u = false,
                                                   bool head_done = false, const ScaleOp *tail_then = nullptr, const XBc<T> *xbc = nullptr,
-                                                  bool *xdone = nullptr) {
+                                                  bool *xdone = nullptr, T *uvel = nullptr) {
     const G g = mkG(&a->d.g);
+    T *const uv = uvel ? uvel : (T *)a->d.u;
     LevelT<T> p = lvl<T>(b, 0);
     const ScaleOp sc = project_scale<T>(dt_, w);
     const double dts = sc.s;
@@ -420,21 +422,21 @@ template <class T, int D> static int flow_project(wl_flow *a, wl_mg *b, double d
         // z-slabs: the plane of u that div reads above the last owned plane and the planes of x that residual! reads travel in ONE
         // batch on the comm stream (x must carry its `.*= dt` first); the fused kernel runs on the inner planes meanwhile
         if (!head_done) WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
-        if (exchange_u) { WL_TRY((halo_begin2<T>(g, (T *)a->d.u, D, 1, p.g, p.x, 1, 1))); begun = true; }
+        if (exchange_u) { WL_TRY((halo_begin2<T>(g, uv, D, 1, p.g, p.x, 1, 1))); begun = true; }
     } else if (exchange_u && D == 3 && g.dist && overlap_on() && R.hi[2] - R.lo[2] + 1 >= 2) {
-        WL_TRY((halo_begin<T>(g, (T *)a->d.u, D, 1)));
+        WL_TRY((halo_begin<T>(g, uv, D, 1)));
         int rc = head_done ? 0 : op_scale_all<T, D>(g, p.x, dts, false, dbl);
-        if (!rc) rc = op_div<T, D>(g, p.z, (const T *)a->d.u, R.lo[2], R.hi[2] - 1);
+        if (!rc) rc = op_div<T, D>(g, p.z, (const T *)uv, R.lo[2], R.hi[2] - 1);
         WL_TRY(halo_end());   // (always joined, also on an error above)
         if (rc) return rc;
-        WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u, R.hi[2], R.hi[2])));
+        WL_TRY((op_div<T, D>(g, p.z, (const T *)uv, R.hi[2], R.hi[2])));
     } else {
-        if (exchange_u) WL_TRY((halo_exchange<T>(g, (T *)a->d.u, D, 1)));
-        if (!fused_div) WL_TRY((op_div<T, D>(g, p.z, (const T *)a->d.u)));
+        if (exchange_u) WL_TRY((halo_exchange<T>(g, uv, D, 1)));
+        if (!fused_div) WL_TRY((op_div<T, D>(g, p.z, (const T *)uv)));
         if (!head_done) WL_TRY((op_scale_all<T, D>(g, p.x, dts, false, dbl)));
     }
-    WL_TRY((mg_solve<T, D>(b, 1e-4, 32, n_iter, fused_div ? (const T *)a->d.u : nullptr, &g, begun)));
-    WL_TRY((op_correct<T, D>(g, (T *)a->d.u, p.L, p.x, p.rowc, xbc, xdone)));
+    WL_TRY((mg_solve<T, D>(b, 1e-4, 32, n_iter, fused_div ? (const T *)uv : nullptr, &g, begun)));
+    WL_TRY((op_correct<T, D>(g, uv, p.L, p.x, p.rowc, xbc, xdone)));
     return op_scale_all<T, D>(g, p.x, dts, true, dbl, tail_then);
 }
 
@@ -453,6 +455,35 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     // (the x-ghost cells of the interior rows are written by the kernel that produces the row: XBc, wl_set_option(23))
     const XBc<T> xbc{(D == 3 && d.perdir_mask == 0 && ctx().opt[7] && ctx().opt[23]) ? 1 : 0, d.exitBC ? 1 : 0, (T)U[0]};
     bool xd = false;
+    // BDIM! finished inside conv_diff! on the body-free rows (wl_set_option(27), CdFin in wl_convdiff.h).  The kernel that
+    // forms f cannot overwrite the velocity its neighbours still read, so the two velocity arrays take turns: the predictor
+    // reads `u` (which thereby IS u0: no copy) and writes u' into the flow's u0 array; the corrector reads u' there and u0 in
+    // `u`, cell by cell, and writes the new velocity over it.  On return `u` holds the new velocity as always and the u0 ARRAY
+    // holds u' instead of the old velocity -- the reference overwrites u0 before it reads it (Flow.jl:154), see DESIGN.md 7.
+    if constexpr (D == 3) {
+        if (ctx().opt[27] && ctx().opt[3] && a->rowfree && a->busy && d.perdir_mask == 0 && !d.exitBC && conv_diff_tiled<D>(g, 0)) {
+            T *const up = u0;   // u' lives here
+            const XBc<T> xb{xbc.on, 0, xbc.U0};
+            const CdFin<T> fin1{up, a->rowfree, xbc.on, (T)U[0]}, fin2{u, a->rowfree, xbc.on, (T)U[0]};
+            WL_TRY((op_conv_diff<T, D, true, false, 1>(g, f, u, d.nu, 0, u, V, dt, gp, gp != nullptr, nullptr, false, &fin1)));
+            WL_TRY((op_bdim2_busy<T, 1>(g, up, up, f, V, mu0, mu1, a->busy, a->nbusy, xb, true)));
+            WL_TRY((op_bc_vec<T, D>(g, up, U, 0, 0, xbc.on != 0)));
+            const ScaleOp corr_head = project_scale<T>(dt, 0.5);
+            const bool chain = ctx().opt[14] != 0;
+            WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0], true, false, chain ? &corr_head : nullptr, &xbc, &xd, up)));
+            WL_TRY((op_bc_vec<T, D>(g, up, U, 0, 0, xd)));
+            WL_TRY((op_conv_diff<T, D, true, false, 2>(g, f, up, d.nu, 0, u, V, dt, gc, gc != nullptr, nullptr, true, &fin2)));
+            WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, up, d.nu, 0)));   // (Flow.jl:164: Φ of the corrector, from u')
+            WL_TRY((op_bdim2_busy<T, 2>(g, u, up, f, V, mu0, mu1, a->busy, a->nbusy, xb, true)));
+            WL_TRY((op_bc_vec<T, D>(g, u, U, 0, 0, xbc.on != 0)));
+            WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true, chain, nullptr, &xbc, &xd)));
+            WL_TRY((op_bc_vec<T, D>(g, u, U, 0, 0, xd)));
+            WL_TRY((op_cfl<T, D>(g, (T *)d.sigma, u, d.nu, a->sc.partials, a->sc.st, true)));
+            WL_TRY(a->sc.fetch());
+            *dt_next = a->sc.hst->out[0];
+            return 0;
+        }
+    }
     WL_TRY((op_conv_diff<T, D, true, true>(g, f, u, d.nu, d.perdir_mask, nullptr, V, dt, gp, gp != nullptr, u0)));
     // σ's top ghost cells: the flux scratch Φ the reference's conv_diff! leaves there (Flow.jl:157), read by its whole-array
     // z⋅ϵ in the projection that follows (periodic runs only: elsewhere ϵ's ghosts are zero) and by maximum(a.σ) in CFL --

@@ -70,8 +70,8 @@ struct Mailbox {
 
 struct Ctx {
     Mailbox *mbox = nullptr;
-    // wl_set_option (include/wlhip.h); keys 11, 12, 20, 21, 24, 25, 27, 28, 29 are retired (WL_OPT_LIVE)
-    int opt[32] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 0, 0, 1, 1, 0, 0, 600, 0, 0, 0, 1, 1};
+    // wl_set_option (include/wlhip.h); keys 11, 12, 20, 21, 24, 25, 28, 29 are retired (WL_OPT_LIVE)
+    int opt[32] = {1, 1, 1, 1, 0, 2, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 4, 16, 1, 1, 0, 0, 1, 1, 0, 0, 600, 1, 0, 0, 1, 1};
     double wall_khz = 0.0;             // rate of the device's wall clock (mailbox time-outs), read when the mailbox is made
     Comm *comm = nullptr;
     hipStream_t stream = nullptr;
@@ -95,8 +95,8 @@ Ctx &ctx();
 // every allocation of the library goes through these two (counted: a steady time step must not allocate, test/alloctest.jl)
 inline hipError_t wl_dev_alloc(void **p, size_t n) { ctx().n_alloc += 1; ctx().alloc_bytes += (int64_t)n; return hipMalloc(p, n); }
 inline hipError_t wl_host_alloc(void **p, size_t n, unsigned flags) { ctx().n_alloc += 1; ctx().alloc_bytes += (int64_t)n; return hipHostMalloc(p, n, flags); }
-// live wl_set_option keys: 0-10, 13-19, 22, 23, 26, 30, 31
-constexpr unsigned WL_OPT_LIVE = 0xC4CFE7FFu;
+// live wl_set_option keys: 0-10, 13-19, 22, 23, 26, 27, 30, 31
+constexpr unsigned WL_OPT_LIVE = 0xCCCFE7FFu;
 int fail(int code, const char *what, const char *file, int line);
 
 #define WL_HIP(expr)                                                        \

@@ -55,6 +55,38 @@ template <class T, bool GEN = true> __device__ __forceinline__ T cd_sub(T r, dou
     return bnd ? (T)((double)r - F) : r - (T)F;
 }
 
+// FIN (mom_step! only): the kernel also FINISHES BDIM! (Flow.jl:134, then scale_u! :166) on the body-free x-rows -- mu1 = 0,
+// V = 0, mu0 = 1 along the row (`rowfree`, op_bdim2), where the statement is u (+)= f: the new velocity of such a row goes
+// to `unew` straight from the registers that hold f, V is not read there (f = (u0 + dt r) - 0; the load stays unconditional but
+// goes to one fixed address: a value selected around a load would be moved while the load is in flight, and that move waits
+// for every load issued before it), and the row's x-ghost cells
+// of the BC! that follows are written too (XBc).  The separate pass over the body-free rows (read f, read u, write u:
+// 6T / 9T per cell) disappears; the busy rows keep their own kernel.  `unew` must not be the array the stencil reads:
+//   FIN = 1, predictor: u was zeroed (scale_u!(a,0), :154)  -> unew = (0 + f);   u0 IS the stencil input, nothing is copied
+//   FIN = 2, corrector: u' = the stencil input              -> unew = ((u' + f) * 0.5), both roundings kept
+// (the values of op_bdim2's pass over the body-free rows, see cd_fin => bit-identical)
+template <class T> struct CdFin { T *unew; const unsigned char *rowfree; int xon; T U0; };
+// op_bdim2 evaluates the statement as the reference's promotions dictate: tmp = (0.5*0 + 0) + Float64(f); u = T(0 + tmp) or
+// un = T(Float64(u') + tmp), u = T(Float64(un) * 0.5).  The same values in T arithmetic (this kernel is short of VALU cycles,
+// and Float64 adds and conversions run at half rate): tmp = f with -0 turned into +0, i.e. f + 0; a sum of two T values
+// rounded to Float64 and then to T equals the sum rounded to T at once (53 >= 2*24 + 2 bits); a product with 0.5 is exact in
+// both types, and where it is not (subnormal result) both paths round the same exact value to nearest-even.
+template <class T, int FIN> __device__ __forceinline__ T cd_fin(T uold, T fv) {
+    const T tmp = fv + (T)0;
+    if (FIN == 1) return tmp;
+    const T un = uold + tmp;
+    return un * (T)0.5;
+}
+// store a finished cell of component c (+ the row's x-ghost cells: Dirichlet U0 for the normal component on the planes 0, 1
+// and n0-1, the neighbour's value for the other two -- util.jl:200-207 for a non-periodic x without the convective exit)
+template <class T, bool XEDGE = true> __device__ __forceinline__ void cd_fin_store(const CdFin<T> &fn, long o, int c, int i, int n0, T val) {
+    if (XEDGE && fn.xon) {   // (XEDGE = false: the caller knows that its tile holds neither i = 1 nor i = n0-2)
+        if (i == 1) { if (c == 0) val = fn.U0; fn.unew[o - 1] = val; }
+        if (i == n0 - 2) fn.unew[o + 1] = (c == 0) ? fn.U0 : val;
+    }
+    fn.unew[o] = val;
+}
+
 // COPY (predictor, Flow.jl:154): `a.u0 .= a.u` is folded in -- the kernel reads u, writes u0out = u for every cell it
 // owns and uses that value in the BDIM epilogue (saves the separate 6T copy pass).
 // One launch covers up to CD_NSEG boxes of tiles ("segments": a range of planes x a range of tile rows, each with its own
@@ -63,11 +95,11 @@ template <class T, bool GEN = true> __device__ __forceinline__ T cd_sub(T r, dou
 constexpr int CD_NSEG = 4;
 struct CdSeg { int b0, nblk, tpp, clen, ty0, ntile, zlo, zhi; };   // b0: first block of the segment (multiple of 8)
 struct CdSegs { int n; CdSeg s[CD_NSEG]; };
-template <class T, bool FUSE, bool COPY>
+template <class T, bool FUSE, bool COPY, int FIN>
 __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__ r, const T *__restrict__ u, T nu,
                                                            const T *u0, T *u0out, const T *__restrict__ V, T dt,
                                                            double a0, double a1, double a2, bool has_acc, int ntx,
-                                                           CdSegs segs) {
+                                                           CdSegs segs, CdFin<T> fn) {
     __shared__ T sm[3][3][CD_R][CD_W];  // [plane slot][component][row][col]
     const int tx = threadIdx.x & (CD_BX - 1), ty = threadIdx.x / CD_BX;
     CdSeg sg = segs.s[0];
@@ -130,8 +162,14 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
 
     T part[3] = {0, 0, 0};     // carried partial sums of cell k-1 (after x, y and lower-z fluxes)
     T cu0[3] = {0, 0, 0}, cV[3] = {0, 0, 0};
-    bool carry = false;
+    bool carry = false, cfin = false;
     const bool jlow = j >= 1;
+    const bool jin = (j >= 1) && (j <= n1 - 2);
+    // FIN: the row flag of plane k is requested one iteration ahead (a load consumed in the iteration that issues it would
+    // drain every load in flight: vmcnt counts in order)
+    const unsigned char *ffp = fn.rowfree + jc;
+    unsigned char ffl = 0;
+    if (FIN) ffl = ffp[(long)n1 * clampk(k0)];
     const int kend = min(k1, n2 - 1);
 
     for (int k = k0; k <= kend; ++k) {
@@ -139,17 +177,23 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
         // ---- A. issue the global loads of the next planes first
         T nxt[3], hv[2][3], e0[3], eV[3];
         const int kn = clampk(k + 2), kh = clampk(k + 1);
+        const int kg = k + kz0;                 // plane number in the undecomposed array
+        // FIN: is cell k an interior cell of a body-free row?  (wave-uniform: a wavefront works on one row)
+        bool fin = false;
+        if (FIN) { fin = own && jin && kg >= 1 && kg <= nzg - 2 && ffl != 0; ffl = ffp[(long)n1 * kh]; }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             nxt[c] = u[col + sz * kn + sc * c];
 #pragma unroll
             for (int q = 0; q < 2; ++q) if (q < nh) hv[q][c] = u[hg[q] + sz * kh + sc * c];
-            if (FUSE) { e0[c] = COPY ? W[c][2] : u0[col + sz * k + sc * c]; eV[c] = V[col + sz * k + sc * c]; }
+            if (FUSE) {
+                e0[c] = (COPY || FIN == 1) ? W[c][2] : u0[col + sz * k + sc * c];
+                eV[c] = V[(fin ? 0L : col + sz * k) + sc * c];   // (body-free row: V = 0 is not read -- see vsel below)
+            }
             if (COPY && own && active) u0out[col + sz * k + sc * c] = W[c][2];
         }
         // ---- B. fluxes of plane k
         const int s1 = (k + 3) % 3, s0 = (k + 2) % 3;  // LDS slots of planes k and k-1
-        const int kg = k + kz0;                 // plane number in the undecomposed array
         const bool ring = g.zring;              // periodic ring of slabs: every z face is an interior face
         const bool klow = ring || kg >= 1;
         const bool lowok = jlow && klow;
@@ -201,24 +245,26 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
         if (bface) fluxes(std::true_type{}); else fluxes(std::false_type{});
         // ---- C. finish and store: the carried cell k-1 gets its upper z flux; cell k is stored now when it
         //         takes no upper z flux (k == 0, k == n2-1, or j == 0), else it is carried
-        auto emit = [&](int kk, const T(&val)[3], const T(&q0)[3], const T(&qV)[3]) {
+        auto emit = [&](int kk, const T(&val)[3], const T(&q0)[3], const T(&qV)[3], bool fin_, int wq) {   // wq: W slot of plane kk
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 T v = val[c];
                 const long o = col + sz * kk + sc * c;
                 if (FUSE) {
                     if (has_acc) v = (T)((double)v + (c == 0 ? a0 : (c == 1 ? a1 : a2)));
-                    r[o] = (q0[c] + dt * v) - qV[c];
+                    const T fv = (q0[c] + dt * v) - ((FIN && fin_) ? (T)0 : qV[c]);   // vsel
+                    r[o] = fv;
+                    if (FIN) { if (fin_) cd_fin_store<T>(fn, o, c, i, n0, cd_fin<T, FIN>(wq == 1 ? W[c][1] : W[c][2], fv)); }
                 } else {
                     r[o] = v;
                 }
             }
         };
         if (carry) {
-            T fin[3];
+            T done[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) fin[c] = cd_sub<T>(part[c], Fz[c], ztb);
-            if (active) emit(k - 1, fin, cu0, cV);
+            for (int c = 0; c < 3; ++c) done[c] = cd_sub<T>(part[c], Fz[c], ztb);
+            if (active) emit(k - 1, done, cu0, cV, cfin, 1);
             carry = false;
         }
         if (own) {
@@ -226,9 +272,9 @@ __global__ __launch_bounds__(CD_BX *CD_BY) void k_convdiff3(G g, T *__restrict__
             if (needs_up) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { part[c] = rr[c]; cu0[c] = e0[c]; cV[c] = eV[c]; }
-                carry = true;
+                carry = true; cfin = fin;
             } else if (active) {
-                emit(k, rr, e0, eV);
+                emit(k, rr, e0, eV, fin, 2);
             }
         }
         // ---- D. rotate the register window, publish plane k+1 into its LDS slot
@@ -271,10 +317,10 @@ template <class T, int BY> struct CdsShared {
     T yedge[2][3][CD_BX];              // y flux through face j0+BY
     double xedge[2][3][BY];            // x flux through face ie (Float64: the upper x boundary accumulates in it)
 };
-template <class T, bool FUSE, bool COPY, bool GENX, int BY>
+template <class T, bool FUSE, bool COPY, bool GENX, int BY, int FIN>
 __device__ __forceinline__ void convdiff3s_tile(CdsShared<T, BY> &S_, const G &g, T *__restrict__ r, const T *__restrict__ u, T nu, const T *u0,
                                                 T *u0out, const T *__restrict__ V, T dt, double a0, double a1, double a2, bool has_acc,
-                                                int i0, int j0, int ie, int k0, int k1) {
+                                                int i0, int j0, int ie, int k0, int k1, const CdFin<T> &fn) {
     auto &sm = S_.sm; auto &fyb = S_.fyb; auto &yedge = S_.yedge; auto &xedge = S_.xedge;
     const int tx = threadIdx.x & (CD_BX - 1), ty = threadIdx.x / CD_BX;
     const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
@@ -328,7 +374,12 @@ __device__ __forceinline__ void convdiff3s_tile(CdsShared<T, BY> &S_, const G &g
 
     // carried state of cell k-1: its three lower fluxes (rounded to T like the reference's Phi scratch), BDIM operands
     T cfx[3] = {0, 0, 0}, cfy[3] = {0, 0, 0}, cfz[3] = {0, 0, 0}, cu0[3] = {0, 0, 0}, cV[3] = {0, 0, 0};
-    bool carry = false;
+    bool carry = false, cfin = false;
+    // FIN: the row flag of plane k is requested one iteration ahead (a load consumed in the iteration that issues it would
+    // drain every load in flight: vmcnt counts in order)
+    const unsigned char *ffp = fn.rowfree + j;
+    unsigned char ffl = 0;
+    if (FIN) ffl = ffp[(long)n1 * k0];
 
     for (int k = k0; k <= k1; ++k) {
         const bool own = k < k1;
@@ -336,46 +387,85 @@ __device__ __forceinline__ void convdiff3s_tile(CdsShared<T, BY> &S_, const G &g
         // ---- A. issue the global loads of the next planes first
         T nxt[3], hv[2][3], e0[3] = {0, 0, 0}, eV[3] = {0, 0, 0};
         const int kn = clampk(k + 2), kh = clampk(k + 1);
+        // FIN: is (j, k) a body-free row?  (every cell of this kernel is an interior cell; wave-uniform: a wavefront = one row)
+        bool fin = false;
+        if (FIN) { fin = own && ffl != 0; ffl = ffp[(long)n1 * kh]; }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             nxt[c] = u[col + sz * kn + sc * c];
 #pragma unroll
             for (int q = 0; q < 2; ++q) if (q < nh) hv[q][c] = u[hg[q] + sz * kh + sc * c];
-            if (FUSE && own) { e0[c] = COPY ? W[c][2] : u0[col + sz * k + sc * c]; eV[c] = V[col + sz * k + sc * c]; }
+            if (FUSE && own) {
+                e0[c] = (COPY || FIN == 1) ? W[c][2] : u0[col + sz * k + sc * c];
+                eV[c] = V[(fin ? 0L : col + sz * k) + sc * c];   // (body-free row: V = 0 is not read -- see vsel below)
+            }
             if (COPY && own && active) u0out[col + sz * k + sc * c] = W[c][2];
         }
-        // ---- B. lower fluxes of plane k
+        // ---- B0. lower z fluxes of plane k (own column: registers + one LDS operand) = upper z fluxes of the carried cell
         const int s1 = (k + 3) % 3, s0 = (k + 2) % 3;  // LDS slots of planes k and k-1
-        T fx[3], fy[3], fz[3];
+        T fx[3] = {0, 0, 0}, fy[3] = {0, 0, 0}, fz[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const T *P = SM(s1, c) + own_l;  // plane k, component c, centred on the own cell
             double ufz;
             if (c == 0) ufz = (double)((T)(W[2][2] + SM(s1, 2)[own_l - 1]) * (T)0.5);
             else if (c == 1) ufz = (double)((T)(W[2][2] + SM(s1, 2)[own_l - CD_W]) * (T)0.5);
             else ufz = (double)((T)(W[2][2] + W[2][1]) * (T)0.5);
             fz[c] = (T)cd_flux<T, false>(W[c][0], W[c][1], W[c][2], W[c][3], ufz, nu, false, false);
-            fx[c] = (T)0; fy[c] = (T)0;
-            if (!own) continue;               // (plane k1 only finishes cell k1-1: its z flux is all that is needed)
-            const T xm2 = P[-2], xm1 = P[-1], x0 = W[c][2], xp1 = P[1];
-            const T *PX = SM(s1, 0) + own_l;
-            double ufl;
-            if (c == 0) ufl = (double)((T)(PX[0] + PX[-1]) * (T)0.5);
-            else if (c == 1) ufl = (double)((T)(PX[0] + PX[-CD_W]) * (T)0.5);
-            else ufl = (double)((T)(PX[0] + W[0][1]) * (T)0.5);
-            fx[c] = (T)cd_flux<T, GENX>(xm2, xm1, x0, xp1, ufl, nu, xlow && (i == 1), false);
-            const T ym2 = P[-2 * CD_W], ym1 = P[-CD_W], yp1 = P[CD_W];
-            const T *PY = SM(s1, 1) + own_l;
-            double vfl;
-            if (c == 0) vfl = (double)((T)(PY[0] + PY[-1]) * (T)0.5);
-            else if (c == 1) vfl = (double)((T)(PY[0] + PY[-CD_W]) * (T)0.5);
-            else vfl = (double)((T)(PY[0] + W[1][1]) * (T)0.5);
-            fy[c] = (T)cd_flux<T, false>(ym2, ym1, x0, yp1, vfl, nu, false, false);
-            fyb[par][c][ty][tx] = fy[c];
         }
-        // ---- B'. the tile's outermost upper faces, one extra evaluation per wavefront (all operands from LDS):
-        //      wavefronts 0..2: y face j0+BY of column tx for component ty; wavefront 3 (lanes 0..3BY-1): x face ie of row lane/3
+        // ---- C. finish cell k-1 FIRST: its upper fluxes are the lower fluxes of the neighbours of plane k-1 (published last
+        //         iteration) and fz above.  Its stores then have the flux arithmetic of plane k to drain in: the plane loop ends
+        //         on a wait for every outstanding memory operation (the halo values go to LDS), stores included
+        if (carry) {
+            const int pp = par ^ 1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                T fxh = lane_dn1(cfx[c]);
+                const double xe = xedge[pp][c][ty];
+                const bool lastc = (i + 1 == ie);
+                if (lastc) fxh = (T)xe;
+                const T fyh = (ty < BY - 1) ? fyb[pp][c][ty + 1][tx] : yedge[pp][c][tx];
+                T v = (T)0 + cfx[c];
+                v = (GENX && xtop && lastc) ? (T)((double)v - xe) : v - fxh;
+                v = v + cfy[c];
+                v = v - fyh;
+                v = v + cfz[c];
+                v = v - fz[c];
+                if (active) {
+                    const long o = col + sz * (k - 1) + sc * c;
+                    if (FUSE) {
+                        if (has_acc) v = (T)((double)v + (c == 0 ? a0 : (c == 1 ? a1 : a2)));
+                        const T fv = (cu0[c] + dt * v) - ((FIN && cfin) ? (T)0 : cV[c]);   // vsel
+                        r[o] = fv;
+                        if (FIN) { if (cfin) cd_fin_store<T, GENX>(fn, o, c, i, n0, cd_fin<T, FIN>(W[c][1], fv)); }   // (W[.][1]: plane k-1 of u)
+                    } else {
+                        r[o] = v;
+                    }
+                }
+            }
+        }
+        // ---- B. lower x and y fluxes of plane k (plane k1 only finishes cell k1-1: nothing to do)
         if (own) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const T *P = SM(s1, c) + own_l;  // plane k, component c, centred on the own cell
+                const T xm2 = P[-2], xm1 = P[-1], x0 = W[c][2], xp1 = P[1];
+                const T *PX = SM(s1, 0) + own_l;
+                double ufl;
+                if (c == 0) ufl = (double)((T)(PX[0] + PX[-1]) * (T)0.5);
+                else if (c == 1) ufl = (double)((T)(PX[0] + PX[-CD_W]) * (T)0.5);
+                else ufl = (double)((T)(PX[0] + W[0][1]) * (T)0.5);
+                fx[c] = (T)cd_flux<T, GENX>(xm2, xm1, x0, xp1, ufl, nu, xlow && (i == 1), false);
+                const T ym2 = P[-2 * CD_W], ym1 = P[-CD_W], yp1 = P[CD_W];
+                const T *PY = SM(s1, 1) + own_l;
+                double vfl;
+                if (c == 0) vfl = (double)((T)(PY[0] + PY[-1]) * (T)0.5);
+                else if (c == 1) vfl = (double)((T)(PY[0] + PY[-CD_W]) * (T)0.5);
+                else vfl = (double)((T)(PY[0] + W[1][1]) * (T)0.5);
+                fy[c] = (T)cd_flux<T, false>(ym2, ym1, x0, yp1, vfl, nu, false, false);
+                fyb[par][c][ty][tx] = fy[c];
+            }
+            // ---- B'. the tile's outermost upper faces, one extra evaluation per wavefront (all operands from LDS):
+            //      wavefronts 0..2: y face j0+BY of column tx for component ty; wavefront 3 (lanes 0..3BY-1): x face ie of row lane/3
             if (ty < 3) {
                 const int c = ty;
                 const int el = (BY + CD_H) * CD_W + tx + CD_H;        // LDS offset of cell (i0+tx, j0+BY)
@@ -399,34 +489,7 @@ __device__ __forceinline__ void convdiff3s_tile(CdsShared<T, BY> &S_, const G &g
                 xedge[par][c][rr] = cd_flux<T, GENX>(P[-2], P[-1], P[0], fp1, uf, nu, false, xtop);
             }
         }
-        // ---- C. finish cell k-1: upper fluxes = lower fluxes of the neighbours of plane k-1 (published last iteration)
-        if (carry) {
-            const int pp = par ^ 1;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                T fxh = lane_dn1(cfx[c]);
-                const double xe = xedge[pp][c][ty];
-                const bool lastc = (i + 1 == ie);
-                if (lastc) fxh = (T)xe;
-                const T fyh = (ty < BY - 1) ? fyb[pp][c][ty + 1][tx] : yedge[pp][c][tx];
-                T v = (T)0 + cfx[c];
-                v = (GENX && xtop && lastc) ? (T)((double)v - xe) : v - fxh;
-                v = v + cfy[c];
-                v = v - fyh;
-                v = v + cfz[c];
-                v = v - fz[c];
-                if (active) {
-                    const long o = col + sz * (k - 1) + sc * c;
-                    if (FUSE) {
-                        if (has_acc) v = (T)((double)v + (c == 0 ? a0 : (c == 1 ? a1 : a2)));
-                        r[o] = (cu0[c] + dt * v) - cV[c];
-                    } else {
-                        r[o] = v;
-                    }
-                }
-            }
-        }
-        carry = own;
+        carry = own; cfin = fin;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { cfx[c] = fx[c]; cfy[c] = fy[c]; cfz[c] = fz[c]; cu0[c] = e0[c]; cV[c] = eV[c]; }
         // ---- D. rotate the register window, publish plane k+1 into its LDS slot
@@ -443,10 +506,11 @@ __device__ __forceinline__ void convdiff3s_tile(CdsShared<T, BY> &S_, const G &g
 }
 // One launch covers every x tile of the interior tile rows; a tile holding a domain x-boundary face (first / last of a
 // row: uniform per workgroup) runs the copy of the plane loop with the one-sided flux variants (GENX), the others the plain one.
-template <class T, bool FUSE, bool COPY, int BY>
+template <class T, bool FUSE, bool COPY, int BY, int FIN>
 __global__ __launch_bounds__(CD_BX *BY) void k_convdiff3s(G g, T *__restrict__ r, const T *__restrict__ u, T nu, const T *u0, T *u0out,
                                                          const T *__restrict__ V, T dt, double a0, double a1, double a2, bool has_acc,
-                                                         int ntx, int tpp, int nblk, int clen, int jbase, int klo, int khi, int ntile, int rev) {
+                                                         int ntx, int tpp, int nblk, int clen, int jbase, int klo, int khi, int ntile, int rev,
+                                                         CdFin<T> fn) {
     // (dynamic LDS: CdsShared<double, 8> is 86.6 KB -- more than the 64 KB a static __shared__ object may take)
     extern __shared__ __attribute__((aligned(16))) unsigned char cds_raw[];
     CdsShared<T, BY> &S_ = *reinterpret_cast<CdsShared<T, BY> *>(cds_raw);
@@ -460,8 +524,8 @@ __global__ __launch_bounds__(CD_BX *BY) void k_convdiff3s(G g, T *__restrict__ r
     const int k0 = klo + ch * clen, k1 = min(khi + 1, k0 + clen);      // this chunk of planes (all z faces interior)
     if (k0 > khi || pt >= ntile || j0 + BY - 1 > n1 - 3 || i0 > n0 - 2) return;   // uniform per workgroup (padding tiles)
     const int ie = min(i0 + CD_BX, n0 - 1);       // the x face beyond the tile's last cell
-    if (i0 == 1 || ie == n0 - 1) convdiff3s_tile<T, FUSE, COPY, true, BY>(S_, g, r, u, nu, u0, u0out, V, dt, a0, a1, a2, has_acc, i0, j0, ie, k0, k1);
-    else convdiff3s_tile<T, FUSE, COPY, false, BY>(S_, g, r, u, nu, u0, u0out, V, dt, a0, a1, a2, has_acc, i0, j0, ie, k0, k1);
+    if (i0 == 1 || ie == n0 - 1) convdiff3s_tile<T, FUSE, COPY, true, BY, FIN>(S_, g, r, u, nu, u0, u0out, V, dt, a0, a1, a2, has_acc, i0, j0, ie, k0, k1, fn);
+    else convdiff3s_tile<T, FUSE, COPY, false, BY, FIN>(S_, g, r, u, nu, u0, u0out, V, dt, a0, a1, a2, has_acc, i0, j0, ie, k0, k1, fn);
 }
 
 // host side.  One tile row = CD_BY rows of cells starting at j0 = CD_BY*ty; the shared-flux kernel takes the tile rows
@@ -469,9 +533,9 @@ __global__ __launch_bounds__(CD_BX *BY) void k_convdiff3s(G g, T *__restrict__ r
 // only (global plane 2 .. nzg-3; every plane on a periodic ring of slabs); k_convdiff3 takes the first / last tile row
 // and the boundary planes; the two x-ghost planes go through the generic gather kernel (caller).
 struct CdBox { int zlo, zhi, ty0, nty; };   // planes [zlo, zhi] x tile rows [ty0, ty0+nty)
-template <class T, bool FUSE, bool COPY>
+template <class T, bool FUSE, bool COPY, int FIN>
 int launch_convdiff3_old(const G &g, const CdBox *box, int nbox, T *r, const T *u, double nu_, const T *u0, T *u0out, const T *V,
-                         double dt_, const double (&a3)[3], bool has_acc) {
+                         double dt_, const double (&a3)[3], bool has_acc, const CdFin<T> &fn) {
     const int ntx = (g.n[0] - 2 + CD_BX - 1) / CD_BX;
     CdSegs segs;
     segs.n = 0;
@@ -495,13 +559,14 @@ int launch_convdiff3_old(const G &g, const CdBox *box, int nbox, T *r, const T *
     if (!segs.n) return 0;
     for (int q = segs.n; q < CD_NSEG; ++q) segs.s[q] = segs.s[0];
     Prof p(WL_K_CONVDIFF, cells);
-    hipLaunchKernelGGL((k_convdiff3<T, FUSE, COPY>), dim3(nblk), dim3(CD_BX * CD_BY), 0, ctx().stream, g, r, u, (T)nu_, u0,
-                       u0out, V, (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, segs);
+    hipLaunchKernelGGL((k_convdiff3<T, FUSE, COPY, FIN>), dim3(nblk), dim3(CD_BX * CD_BY), 0, ctx().stream, g, r, u, (T)nu_, u0,
+                       u0out, V, (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, segs, fn);
     return (int)hipGetLastError();
 }
-template <class T, bool FUSE, bool COPY>
+template <class T, bool FUSE, bool COPY, int FIN = 0>
 int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u0out, const T *V, double dt_,
-                     const double *acc, bool has_acc) {
+                     const double *acc, bool has_acc, const CdFin<T> &fn = CdFin<T>{nullptr, nullptr, 0, (T)0}) {
+    static_assert(FIN == 0 || (FUSE && !COPY), "FIN finishes BDIM!: it needs the fused epilogue and copies nothing");
     double a3[3] = {0, 0, 0};
     if (has_acc) for (int d = 0; d < 3; ++d) a3[d] = acc[d];
     const int ntx = (g.n[0] - 2 + CD_BX - 1) / CD_BX, nty_all = (g.n[1] + CD_BY - 1) / CD_BY;
@@ -520,14 +585,14 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
     const bool shared = ctx().opt[18] != 0 && thi_s >= tlo && khi >= klo;
     if (!shared) {
         const CdBox all{g.zlo, g.zhi, 0, nty_all};
-        return launch_convdiff3_old<T, FUSE, COPY>(g, &all, 1, r, u, nu_, u0, u0out, V, dt_, a3, has_acc);
+        return launch_convdiff3_old<T, FUSE, COPY, FIN>(g, &all, 1, r, u, nu_, u0, u0out, V, dt_, a3, has_acc, fn);
     }
     thi = thi_s;
     // (1)+(2) the shell, ONE launch of the per-cell kernel: boundary planes (every tile row), and on the interior planes
     // the first / last tile rows
     const CdBox shell[4] = {{g.zlo, klo - 1, 0, nty_all}, {khi + 1, g.zhi, 0, nty_all},
                             {klo, khi, 0, tlo}, {klo, khi, thi + 1, nty_all - (thi + 1)}};
-    WL_TRY((launch_convdiff3_old<T, FUSE, COPY>(g, shell, 4, r, u, nu_, u0, u0out, V, dt_, a3, has_acc)));
+    WL_TRY((launch_convdiff3_old<T, FUSE, COPY, FIN>(g, shell, 4, r, u, nu_, u0, u0out, V, dt_, a3, has_acc, fn)));
     // (3) interior planes, interior tile rows: shared-flux kernel; x-boundary tiles in a launch of their own (GENX)
     const int nty = thi - tlo + 1;
     const int nown = khi - klo + 1;
@@ -547,8 +612,8 @@ int launch_convdiff3(const G &g, T *r, const T *u, double nu_, const T *u0, T *u
         Prof p(WL_K_CONVDIFF, (long)g.n[0] * (long)(ntr * BY) * nown);
         constexpr size_t lds = sizeof(CdsShared<T, BY>);
         static_assert(lds <= 64 * 1024, "conv_diff tile: more LDS than a launch gets without opting in");
-        hipLaunchKernelGGL((k_convdiff3s<T, FUSE, COPY, BY>), dim3(nblk), dim3(CD_BX * BY), lds, ctx().stream, g, r, u, (T)nu_, u0, u0out, V,
-                           (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen, jbase, klo, khi, ntile, rev);
+        hipLaunchKernelGGL((k_convdiff3s<T, FUSE, COPY, BY, FIN>), dim3(nblk), dim3(CD_BX * BY), lds, ctx().stream, g, r, u, (T)nu_, u0, u0out, V,
+                           (T)dt_, a3[0], a3[1], a3[2], has_acc, ntx, tpp, nblk, clen, jbase, klo, khi, ntile, rev, fn);
         return (int)hipGetLastError();
     };
     const int rows = nty * CD_BY, jb0 = tlo * CD_BY;

@@ -429,31 +429,51 @@ int launch_convdiff_xghost(const G &g, T *r, const T *u, double nu_, const T *u0
 // COPY: also perform `u0 .= u` (Flow.jl:154) for the cells written (u0out), the epilogue then uses u itself.
 // exchange_u (z-slab runs): the 2-plane halo exchange of u that has to precede this call is issued HERE, on the comm
 // stream, and the LDS kernel runs on the planes that read no halo plane (zlo+2 .. zhi-2) while it is in flight.
-template <class T, int D, bool FUSE, bool COPY = false>
+// does op_conv_diff take the LDS-tiled kernels for this grid?
+template <int D> inline bool conv_diff_tiled(const G &g, int permask) {
+    return D == 3 && ctx().opt[2] && (permask == 0 || (permask == 4 && g.zring)) && g.n[0] >= 5 && g.n[1] >= 5 && g.n[2] >= 5;
+}
+// FIN (1 predictor / 2 corrector, with `fin`): the tiled kernels also finish BDIM! on the body-free rows (CdFin, wl_convdiff.h);
+// only where conv_diff_tiled() holds.  The corrector's `fin->unew` is the array `u0` points to (every cell is read by the thread
+// that writes it), so the x-ghost planes -- which read u0 in cells the row kernels overwrite with BC! values -- go first.
+template <class T, int D, bool FUSE, bool COPY = false, int FIN = 0>
 int op_conv_diff(const G &g, T *r, const T *u, double nu_, int permask, const T *u0, const T *V, double dt_,
-                 const double *acc, bool has_acc, T *u0out = nullptr, bool exchange_u = false) {
+                 const double *acc, bool has_acc, T *u0out = nullptr, bool exchange_u = false, const CdFin<T> *fin = nullptr) {
     if constexpr (D == 3) {
-        if (ctx().opt[2] && (permask == 0 || (permask == 4 && g.zring)) && g.n[0] >= 5 && g.n[1] >= 5 && g.n[2] >= 5) {
+        if (conv_diff_tiled<D>(g, permask)) {
+            const CdFin<T> fn = (FIN && fin) ? *fin : CdFin<T>{nullptr, nullptr, 0, (T)0};
+            if (FIN && (!fin || !fin->unew || !fin->rowfree || (const T *)fin->unew == u))
+                return fail(WL_E_STATE, "conv_diff!: finishing BDIM! needs the row flags and an output that is not the stencil input", __FILE__, __LINE__);
             if (exchange_u && g.dist && overlap_on() && g.zhi - g.zlo + 1 >= 5) {
                 WL_TRY((halo_begin<T>(g, const_cast<T *>(u), D, 2)));
                 G gi = g;
                 gi.zlo = g.zlo + 2; gi.zhi = g.zhi - 2;
-                const int rc = launch_convdiff3<T, FUSE, COPY>(gi, r, u, nu_, u0, u0out, V, dt_, acc, has_acc);
+                int rc = 0;
+                if (FIN == 2) rc = launch_convdiff_xghost<T, FUSE, COPY>(gi, r, u, nu_, u0, V, dt_, acc, has_acc, u0out);
+                if (!rc) rc = launch_convdiff3<T, FUSE, COPY, FIN>(gi, r, u, nu_, u0, u0out, V, dt_, acc, has_acc, fn);
                 WL_TRY(halo_end());
                 if (rc) return rc;
                 G gl = g, gh = g;
                 gl.zhi = g.zlo + 1; gh.zlo = g.zhi - 1;
-                WL_TRY((launch_convdiff3<T, FUSE, COPY>(gl, r, u, nu_, u0, u0out, V, dt_, acc, has_acc)));
-                WL_TRY((launch_convdiff3<T, FUSE, COPY>(gh, r, u, nu_, u0, u0out, V, dt_, acc, has_acc)));
+                if (FIN == 2) {
+                    WL_TRY((launch_convdiff_xghost<T, FUSE, COPY>(gl, r, u, nu_, u0, V, dt_, acc, has_acc, u0out)));
+                    WL_TRY((launch_convdiff_xghost<T, FUSE, COPY>(gh, r, u, nu_, u0, V, dt_, acc, has_acc, u0out)));
+                }
+                WL_TRY((launch_convdiff3<T, FUSE, COPY, FIN>(gl, r, u, nu_, u0, u0out, V, dt_, acc, has_acc, fn)));
+                WL_TRY((launch_convdiff3<T, FUSE, COPY, FIN>(gh, r, u, nu_, u0, u0out, V, dt_, acc, has_acc, fn)));
+                if (FIN == 2) return 0;
             } else {
                 if (exchange_u) WL_TRY((halo_exchange<T>(g, const_cast<T *>(u), D, 2)));
-                WL_TRY((launch_convdiff3<T, FUSE, COPY>(g, r, u, nu_, u0, u0out, V, dt_, acc, has_acc)));
+                if (FIN == 2) WL_TRY((launch_convdiff_xghost<T, FUSE, COPY>(g, r, u, nu_, u0, V, dt_, acc, has_acc, u0out)));
+                WL_TRY((launch_convdiff3<T, FUSE, COPY, FIN>(g, r, u, nu_, u0, u0out, V, dt_, acc, has_acc, fn)));
+                if (FIN == 2) return 0;
             }
             // (the two x-ghost planes -- strided, latency-bound, 0.07 + 0.21 ms at 512^3 -- were also tried on a side stream
             //  next to the LDS kernel: no gain, 29.73 vs 29.74 ms per step)
             return launch_convdiff_xghost<T, FUSE, COPY>(g, r, u, nu_, u0, V, dt_, acc, has_acc, u0out);
         }
     }
+    if (FIN) return fail(WL_E_STATE, "conv_diff!: finishing BDIM! needs the tiled kernels", __FILE__, __LINE__);
     if (exchange_u) WL_TRY((halo_exchange<T>(g, const_cast<T *>(u), D, 2)));
     return op_conv_diff_range<T, D, FUSE, COPY>(g, r_whole(g), r, u, nu_, permask, u0, V, dt_, acc, has_acc, u0out);
 }
@@ -492,8 +512,8 @@ _Pragma("unroll")
 // scale_u!(a,0.5) (:166) -> u = 0.5*(u + ...), both roundings kept.
 // general BDIM! statement on a compact list of rows (row = j + n1*k), one wavefront per 64-cell row segment
 template <class T, int MODE>
-__global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *f, const T *V, const T *mu0, const T *mu1,
-                                                    const int *rows, int nrows, int ntx, XBc<T> xb) {
+__global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *uin, const T *f, const T *V, const T *mu0, const T *mu1,
+                                                    const int *rows, int nrows, int ntx, XBc<T> xb) {   // uin: the u that is read (MODE 0, 2)
     const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= (long)nrows * ntx) return;
     const int row = rows[w / ntx];
@@ -514,7 +534,7 @@ __global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *f, const
         const double tmp = (0.5 * (double)s + (double)V[q]) + (double)(T)(mu0[q] * fc[I]);
         T val;
         if (MODE == 1) val = (T)(0.0 + tmp);
-        else { const T un = (T)((double)u[q] + tmp); val = (MODE == 2) ? (T)((double)un * 0.5) : un; }
+        else { const T un = (T)((double)uin[q] + tmp); val = (MODE == 2) ? (T)((double)un * 0.5) : un; }
         if (xb.on) {   // the row's x-ghost cells (see XBc)
             if (i == 1) { if (c == 0) val = xb.U0; u[q - 1] = val; }
             if (i == g.n[0] - 2 && !(c == 0 && xb.saveexit)) u[q + 1] = (c == 0) ? xb.U0 : val;
@@ -523,6 +543,20 @@ __global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *f, const
     }
 }
 
+// the busy rows alone, out of place: the body-free rows were finished by conv_diff! (CdFin); z-slab runs exchange f's
+// plane first (mu_ddn reads f[I +- dz])
+template <class T, int MODE>
+int op_bdim2_busy(const G &g, T *u, const T *uin, const T *f, const T *V, const T *mu0, const T *mu1, const int *busy, int nbusy,
+                  const XBc<T> &xb, bool exchange_f) {
+    if (exchange_f) WL_TRY((halo_exchange<T>(g, const_cast<T *>(f), 3, 1)));
+    if (nbusy == 0) return 0;
+    const int ntx = (g.n[0] - 2 + 63) / 64;
+    const long nw = (long)nbusy * ntx;
+    Prof p(WL_K_BDIM, (long)nbusy * (g.n[0] - 2));
+    hipLaunchKernelGGL((k_bdim2_busy<T, MODE>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx().stream, g, u, uin, f, V, mu0, mu1, busy,
+                       nbusy, ntx, xb);
+    return (int)hipGetLastError();
+}
 // `rowfree` (optional, mom_step! only): rowfree[j + n1*k] != 0 means mu1 == 0, V == 0 and mu0 == 1 on x-row (j,k), so
 // the statement reduces to u (+)= f -- same value, 15 coefficient reads and 6 neighbour reads per cell skipped.
 // exchange_f (z-slab runs): the 1-plane halo exchange of f that mu_ddn needs is issued HERE on the comm stream; the pass
@@ -548,7 +582,7 @@ int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu
                 const int ntx = (g.n[0] - 2 + 63) / 64;
                 const long nw = (long)nbusy * ntx;
                 Prof p(WL_K_BDIM, (long)nbusy * (g.n[0] - 2));
-                hipLaunchKernelGGL((k_bdim2_busy<T, MODE>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx().stream, g, u, f, V,
+                hipLaunchKernelGGL((k_bdim2_busy<T, MODE>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx().stream, g, u, (const T *)u, f, V,
                                    mu0, mu1, busy, nbusy, ntx, xb);
                 return (int)hipGetLastError();
             };
