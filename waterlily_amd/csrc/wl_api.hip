@@ -262,6 +262,7 @@ struct wl_flow {
     unsigned char *rowbuf = nullptr;
     int *busy = nullptr;                // compact list of the busy interior rows (j + n1*k), device
     int nbusy = 0;
+    int nbusy_lo = 0, nbusy_hi = 0;      // how many of them lie in the first / last owned interior plane (the list is sorted by plane)
     size_t busy_cap = 0;
     // native measure! (wl_measure.h): per-row band counts / offsets, rows touched by this and by the previous measure!
     int *rowcount = nullptr;
@@ -466,7 +467,7 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
             const XBc<T> xb{xbc.on, 0, xbc.U0};
             const CdFin<T> fin1{up, a->rowfree, xbc.on, (T)U[0]}, fin2{u, a->rowfree, xbc.on, (T)U[0]};
             WL_TRY((op_conv_diff<T, D, true, false, 1>(g, f, u, d.nu, 0, u, V, dt, gp, gp != nullptr, nullptr, false, &fin1)));
-            WL_TRY((op_bdim2_busy<T, 1>(g, up, up, f, V, mu0, mu1, a->busy, a->nbusy, xb, true)));
+            WL_TRY((op_bdim2_busy<T, 1>(g, up, up, f, V, mu0, mu1, a->busy, a->nbusy, a->nbusy_lo, a->nbusy_hi, xb)));
             WL_TRY((op_bc_vec<T, D>(g, up, U, 0, 0, xbc.on != 0)));
             const ScaleOp corr_head = project_scale<T>(dt, 0.5);
             const bool chain = ctx().opt[14] != 0;
@@ -474,7 +475,7 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
             WL_TRY((op_bc_vec<T, D>(g, up, U, 0, 0, xd)));
             WL_TRY((op_conv_diff<T, D, true, false, 2>(g, f, up, d.nu, 0, u, V, dt, gc, gc != nullptr, nullptr, true, &fin2)));
             WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, up, d.nu, 0)));   // (Flow.jl:164: Φ of the corrector, from u')
-            WL_TRY((op_bdim2_busy<T, 2>(g, u, up, f, V, mu0, mu1, a->busy, a->nbusy, xb, true)));
+            WL_TRY((op_bdim2_busy<T, 2>(g, u, up, f, V, mu0, mu1, a->busy, a->nbusy, a->nbusy_lo, a->nbusy_hi, xb)));
             WL_TRY((op_bc_vec<T, D>(g, u, U, 0, 0, xbc.on != 0)));
             WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true, chain, nullptr, &xbc, &xd)));
             WL_TRY((op_bc_vec<T, D>(g, u, U, 0, 0, xd)));
@@ -692,6 +693,11 @@ static int flow_compact_busy(wl_flow *a, const G &g, int D) {
     if (!list.empty()) WL_HIP(hipMemcpyAsync(a->busy, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, ctx().stream));
     WL_HIP(hipStreamSynchronize(ctx().stream));
     a->nbusy = (int)list.size();
+    a->nbusy_lo = a->nbusy_hi = 0;
+    if (D > 2 && R.hi[2] > R.lo[2])
+        for (int row : list) { a->nbusy_lo += (row / g.n[1] == R.lo[2]); a->nbusy_hi += (row / g.n[1] == R.hi[2]); }
+    else
+        a->nbusy_lo = a->nbusy;   // a single plane: every row reads both neighbours
     return 0;
 }
 template <class T, int D> static int flow_update(wl_flow *a) {

@@ -543,19 +543,29 @@ __global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *uin, con
     }
 }
 
-// the busy rows alone, out of place: the body-free rows were finished by conv_diff! (CdFin); z-slab runs exchange f's
-// plane first (mu_ddn reads f[I +- dz])
+// the busy rows alone, out of place: the body-free rows were finished by conv_diff! (CdFin).  z-slab runs: mu_ddn reads
+// f[I +- dz], so f's plane travels first -- on the comm stream, while the busy rows of the planes that read no halo plane are
+// done (the list is sorted by plane: the first nlo rows lie in the first owned interior plane, the last nhi in the last one)
 template <class T, int MODE>
 int op_bdim2_busy(const G &g, T *u, const T *uin, const T *f, const T *V, const T *mu0, const T *mu1, const int *busy, int nbusy,
-                  const XBc<T> &xb, bool exchange_f) {
-    if (exchange_f) WL_TRY((halo_exchange<T>(g, const_cast<T *>(f), 3, 1)));
-    if (nbusy == 0) return 0;
+                  int nlo, int nhi, const XBc<T> &xb) {
     const int ntx = (g.n[0] - 2 + 63) / 64;
-    const long nw = (long)nbusy * ntx;
-    Prof p(WL_K_BDIM, (long)nbusy * (g.n[0] - 2));
-    hipLaunchKernelGGL((k_bdim2_busy<T, MODE>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx().stream, g, u, uin, f, V, mu0, mu1, busy,
-                       nbusy, ntx, xb);
-    return (int)hipGetLastError();
+    auto rows = [&](int first, int n) -> int {
+        if (n <= 0) return 0;
+        const long nw = (long)n * ntx;
+        Prof p(WL_K_BDIM, (long)n * (g.n[0] - 2));
+        hipLaunchKernelGGL((k_bdim2_busy<T, MODE>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx().stream, g, u, uin, f, V, mu0, mu1,
+                           busy + first, n, ntx, xb);
+        return (int)hipGetLastError();
+    };
+    Comm *cm = ctx().comm;
+    if (!(g.dist && cm && cm->size > 1) || nlo + nhi > nbusy) return rows(0, nbusy);
+    WL_TRY((halo_begin<T>(g, const_cast<T *>(f), 3, 1)));   // (in-stream when overlap is off)
+    const int rc = rows(nlo, nbusy - nlo - nhi);
+    WL_TRY(halo_end());
+    if (rc) return rc;
+    WL_TRY(rows(0, nlo));
+    return rows(nbusy - nhi, nhi);
 }
 // `rowfree` (optional, mom_step! only): rowfree[j + n1*k] != 0 means mu1 == 0, V == 0 and mu0 == 1 on x-row (j,k), so
 // the statement reduces to u (+)= f -- same value, 15 coefficient reads and 6 neighbour reads per cell skipped.
