@@ -59,8 +59,11 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # bytes it has to move per cell = need + (1 - phi) * extra, phi = share of coefficient-uniform rows (0.94 for the 512^3 sphere)
 ALG_T = {
     #                  dense   need    extra
-    "conv_diff":      (12.0,   12.0,   0.0),   # u0.=u + conv_diff! + accelerate! + BDIM!#1: u(3),V(3) [+u0(3)] -> f(3) [+u0(3)]
-    "bdim":           (22.5,   7.5,    15.0),  # BDIM!#2: f(3) [+u(3)] -> u(3); busy rows also V(3), mu0(3), mu1(9)
+    # u0.=u + conv_diff! + accelerate! + BDIM! (#1 everywhere, #2 + scale_u! on the body-free rows: the velocity arrays take
+    # turns).  predictor: u(3) -> f(3), u'(3); corrector: u'(3), u0(3) -> f(3), u(3): mean of the two
+    # launches of a step; V(3) only in the rows that hold a body (priced with the uniform-row share, which is that share)
+    "conv_diff":      (34.5,   10.5,   3.0),
+    "bdim":           (22.5,   22.5,   0.0),   # BDIM!#2 on the busy rows alone: u(3), f(3), V(3), mu0(3), mu1(9) -> u(3)
     "pcg_mult_dot":   (6.0,    2.0,    3.0),   # eps -> z (+ z.eps); L(3) in non-uniform rows; D recomputed
     "pcg_update":     (13 / 3, 3.5,    5 / 6), # 5 of 6: r,z -> r (+ r.(r iD)); the 6th: x,eps,r,z -> x,r
     "pcg_direction":  (6.0,    5.0,    1.0),   # x,eps,r -> x,eps
