@@ -22,7 +22,10 @@ from waterlily_amd.body import AutoBody, norm2  # noqa: E402
 
 
 def main():
-    case = sys.argv[1] if len(sys.argv) > 1 else "sphere_f32"
+    """argv[1]: one case, or several joined by '+' (same transport: they share the process group and the communicator, so the
+    start-up of the ranks -- most of a small case's wall time -- is paid once); rank 0 prints one `RESULT <json>` line per case"""
+    cases = (sys.argv[1] if len(sys.argv) > 1 else "sphere_f32").split("+")
+    case = cases[0]
     if "rcclnet" in case:
         # RCCL itself at N > 1 on a ONE-GPU box: every rank claims to sit on a different host (NCCL_HOSTID), so RCCL pairs the
         # ranks over its socket transport (loopback) instead of refusing two ranks on one device.  Not an xGMI path, but the
@@ -43,6 +46,19 @@ def main():
         dist.init_process_group("gloo")
         wd.init_host()
     rank, size = dist.get_rank(), dist.get_world_size()
+    for case in cases:
+        out = run_case(case, rank, size)
+        if out is not None and rank == 0:
+            print("RESULT " + json.dumps(dict(out, case=case)), flush=True)
+        dist.barrier()
+    if any(c.startswith("mboxtimeout") for c in cases):
+        _lib.lib().wl_comm_finalize()       # (the mailbox's error flag is sticky: the return code says so again)
+    else:
+        wd.finalize()
+    dist.destroy_process_group()
+
+
+def run_case(case, rank, size):
     T = np.float64 if case.endswith("f64") else np.float32
     m = 512 if "big" in case else (40 if "five" in case else 32)     # (40 = 5 * 2^3: five slabs of 8, 4, 2 planes)
     dims = (m, m, m) if "long" not in case else ((2 * m, 2 * m, 4 * m) if "vlong" in case else (m, m, 2 * m))
@@ -80,17 +96,14 @@ def main():
     if case.startswith("arlat"):
         us = C.c_double()
         _lib.check(_lib.lib().wl_prof_allreduce_us(500, C.byref(us)))
-        out = {"us_per_allreduce": us.value, "mailbox": wd.mailbox_active(), "ranks": size}
-        dist.barrier()
-        wd.finalize()
-        if rank == 0:
-            print("RESULT " + json.dumps(out), flush=True)
-        dist.destroy_process_group()
-        return
+        return {"us_per_allreduce": us.value, "mailbox": wd.mailbox_active(), "ranks": size}
     # "oblique": a stream with a large component along z leaves conv_diff!'s flux scratch ~ w^2 in sigma's ghost cells of the exit
     # plane, above every interior flux_out: the whole-array maximum(a.sigma) of CFL (Flow.jl:174) is a GHOST cell, found by the
     # shell reduction of whichever rank owns it
     ubc = (0.5, 1.0, 4.0) if "oblique" in case else (1.0, 0.0, 0.0)
+    nov_c = C.c_int64()
+    _lib.check(_lib.lib().wl_prof_overlapped(C.byref(nov_c)))
+    nov0 = int(nov_c.value)                     # (the counter runs over the whole process: several cases may share it)
     ref = S.Simulation(dims, ubc, L, slab=None, **kw)
     slab = wd.Slab(rank, size, dims[2], ring=(2 in perdir))
     # "deep": keep every level a slab as long as the partition allows; default: replicate levels <= 2^21 cells
@@ -135,7 +148,7 @@ def main():
         out["d_" + k] = float(np.max(np.abs(a - b)) / max(1e-30, np.max(np.abs(b))))
     nov = C.c_int64()
     _lib.check(_lib.lib().wl_prof_overlapped(C.byref(nov)))
-    out["overlapped"] = int(nov.value)
+    out["overlapped"] = int(nov.value) - nov0
     out["force_ref"] = S.pressure_force(ref).tolist()
     out["force_slab"] = S.pressure_force(sim).tolist()
     # collectives of ONE more step, counted by the library (wl_prof_comm), and the V-cycle counts of its two solves
@@ -145,10 +158,7 @@ def main():
     out["mailbox"] = wd.mailbox_active()
     out["n_counted"] = sim.pois.n[-2:]
     out["slab_nzl"] = [l.layout.slab.nzl if l.layout.slab is not None else None for l in sim.pois.levels]
-    wd.finalize()
-    if rank == 0:
-        print("RESULT " + json.dumps(out), flush=True)
-    dist.destroy_process_group()
+    return out
 
 
 def mailbox_timeout(rank, size):
@@ -168,11 +178,7 @@ def mailbox_timeout(rank, size):
             raised, msg = True, str(e)
     else:
         time.sleep(4.0)
-    dist.barrier()
-    Lb.wl_comm_finalize()
-    if rank == 0:
-        print("RESULT " + json.dumps({"ok_sum": bool(ok_sum), "raised": raised, "msg": msg}), flush=True)
-    dist.destroy_process_group()
+    return {"ok_sum": bool(ok_sum), "raised": raised, "msg": msg}
 
 
 def vtk_roundtrip(rank, size, dims, L, kw):
@@ -209,10 +215,7 @@ def vtk_roundtrip(rank, size, dims, L, kw):
     res = [None] * size
     dist.all_gather_object(res, out["same_local_u"])
     out["same_local_u"] = all(res)
-    wd.finalize()
-    if rank == 0:
-        print("RESULT " + json.dumps(out), flush=True)
-    dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":
