@@ -448,60 +448,60 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     const wl_flow_desc &d = a->d;
     const G g = mkG(&d.g);
     T *u = (T *)d.u, *u0 = (T *)d.u0, *f = (T *)d.f, *V = (T *)d.V, *mu0 = (T *)d.mu0, *mu1 = (T *)d.mu1;
-    const size_t vbytes = (size_t)((long)(D - 1) * g.sc + span(g)) * sizeof(T);
-    (void)vbytes;
-    // predictor (:157-161): a.u0 .= a.u (:154) + conv_diff! + accelerate! + BDIM! #1 in ONE kernel (it reads u, writes
-    // u0 and f); scale_u!(a,0) is folded into the predictor BDIM #2 (MODE 1).
     // (z-slab runs: u carries a 2-plane halo for QUICK, f a 1-plane halo for mu_ddn; exchanges are no-ops otherwise)
     // (the x-ghost cells of the interior rows are written by the kernel that produces the row: XBc, wl_set_option(23))
     const XBc<T> xbc{(D == 3 && d.perdir_mask == 0 && ctx().opt[7] && ctx().opt[23]) ? 1 : 0, d.exitBC ? 1 : 0, (T)U[0]};
     bool xd = false;
-    // BDIM! finished inside conv_diff! on the body-free rows (wl_set_option(27), CdFin in wl_convdiff.h).  The kernel that
-    // forms f cannot overwrite the velocity its neighbours still read, so the two velocity arrays take turns: the predictor
+    // `turns`: BDIM! is finished inside conv_diff! on the body-free rows (wl_set_option(27), CdFin in wl_convdiff.h).  The kernel
+    // that forms f cannot overwrite the velocity its neighbours still read, so the two velocity arrays take turns: the predictor
     // reads `u` (which thereby IS u0: no copy) and writes u' into the flow's u0 array; the corrector reads u' there and u0 in
     // `u`, cell by cell, and writes the new velocity over it.  On return `u` holds the new velocity as always and the u0 ARRAY
-    // holds u' instead of the old velocity -- the reference overwrites u0 before it reads it (Flow.jl:154), see DESIGN.md 7.
-    if constexpr (D == 3) {
-        if (ctx().opt[27] && ctx().opt[3] && a->rowfree && a->busy && d.perdir_mask == 0 && !d.exitBC && conv_diff_tiled<D>(g, 0)) {
-            T *const up = u0;   // u' lives here
-            const XBc<T> xb{xbc.on, 0, xbc.U0};
-            const CdFin<T> fin1{up, a->rowfree, xbc.on, (T)U[0]}, fin2{u, a->rowfree, xbc.on, (T)U[0]};
+    // holds u' instead of the old velocity -- the reference overwrites u0 before it reads it (Flow.jl:154), DESIGN.md 7.8.
+    // Otherwise (2-D, periodic directions, convective exit, no row flags): `a.u0 .= a.u` rides in the predictor's conv_diff!
+    // and BDIM! #2 is a pass of its own, in place.
+    bool turns = false;
+    if constexpr (D == 3)
+        turns = ctx().opt[27] && ctx().opt[3] && a->rowfree && a->busy && d.perdir_mask == 0 && !d.exitBC && conv_diff_tiled<D>(g, 0);
+    T *const up = turns ? u0 : u;   // where the predictor's velocity u' lives
+    const CdFin<T> fin1{up, a->rowfree, xbc.on, (T)U[0]}, fin2{u, a->rowfree, xbc.on, (T)U[0]};
+    (void)fin1; (void)fin2;
+    // predictor (:157-161): [u0 .= u (:154)] + conv_diff! + accelerate! + BDIM! #1 in ONE kernel; scale_u!(a,0) is folded into
+    // BDIM! #2 (MODE 1: u = ...)
+    if (turns) {
+        if constexpr (D == 3) {
             WL_TRY((op_conv_diff<T, D, true, false, 1>(g, f, u, d.nu, 0, u, V, dt, gp, gp != nullptr, nullptr, false, &fin1)));
-            WL_TRY((op_bdim2_busy<T, 1>(g, up, up, f, V, mu0, mu1, a->busy, a->nbusy, a->nbusy_lo, a->nbusy_hi, xb)));
-            WL_TRY((op_bc_vec<T, D>(g, up, U, 0, 0, xbc.on != 0)));
-            const ScaleOp corr_head = project_scale<T>(dt, 0.5);
-            const bool chain = ctx().opt[14] != 0;
-            WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0], true, false, chain ? &corr_head : nullptr, &xbc, &xd, up)));
-            WL_TRY((op_bc_vec<T, D>(g, up, U, 0, 0, xd)));
-            WL_TRY((op_conv_diff<T, D, true, false, 2>(g, f, up, d.nu, 0, u, V, dt, gc, gc != nullptr, nullptr, true, &fin2)));
-            WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, up, d.nu, 0)));   // (Flow.jl:164: Φ of the corrector, from u')
-            WL_TRY((op_bdim2_busy<T, 2>(g, u, up, f, V, mu0, mu1, a->busy, a->nbusy, a->nbusy_lo, a->nbusy_hi, xb)));
-            WL_TRY((op_bc_vec<T, D>(g, u, U, 0, 0, xbc.on != 0)));
-            WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true, chain, nullptr, &xbc, &xd)));
-            WL_TRY((op_bc_vec<T, D>(g, u, U, 0, 0, xd)));
-            WL_TRY((op_cfl<T, D>(g, (T *)d.sigma, u, d.nu, a->sc.partials, a->sc.st, true)));
-            WL_TRY(a->sc.fetch());
-            *dt_next = a->sc.hst->out[0];
-            return 0;
+            WL_TRY((op_bdim2_busy<T, 1>(g, up, up, f, V, mu0, mu1, a->busy, a->nbusy, a->nbusy_lo, a->nbusy_hi, xbc)));   // + exchange of f
+            xd = xbc.on != 0;
         }
+    } else {
+        WL_TRY((op_conv_diff<T, D, true, true>(g, f, u, d.nu, d.perdir_mask, nullptr, V, dt, gp, gp != nullptr, u0)));
+        // σ's top ghost cells: the flux scratch Φ the reference's conv_diff! leaves there (Flow.jl:157), read by its whole-array
+        // z⋅ϵ in the projection that follows (periodic runs only: elsewhere ϵ's ghosts are zero) and by maximum(a.σ) in CFL --
+        // which sees the corrector's values, so a non-periodic run skips the predictor's.
+        if (d.perdir_mask != 0) WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, u, d.nu, d.perdir_mask)));
+        WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd)));   // + exchange of f (overlapped)
     }
-    WL_TRY((op_conv_diff<T, D, true, true>(g, f, u, d.nu, d.perdir_mask, nullptr, V, dt, gp, gp != nullptr, u0)));
-    // σ's top ghost cells: the flux scratch Φ the reference's conv_diff! leaves there (Flow.jl:157), read by its whole-array
-    // z⋅ϵ in the projection that follows (periodic runs only: elsewhere ϵ's ghosts are zero) and by maximum(a.σ) in CFL --
-    // which sees the corrector's values, so a non-periodic run skips the predictor's.
-    if (d.perdir_mask != 0) WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, u, d.nu, d.perdir_mask)));
-    WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd)));   // + exchange of f (overlapped)
-    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
-    if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, u, u0, U, dt, a->sc.partials, a->sc.st)));
+    WL_TRY((op_bc_vec<T, D>(g, up, U, d.exitBC, d.perdir_mask, xd)));
+    if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, up, u0, U, dt, a->sc.partials, a->sc.st)));
     // (the predictor's closing `x ./= dt` and the corrector's opening `x .*= 0.5dt` are ONE pass over x: nothing in between reads p)
     const ScaleOp corr_head = project_scale<T>(dt, 0.5);
     const bool chain = ctx().opt[14] != 0;
-    WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0], true, false, chain ? &corr_head : nullptr, &xbc, &xd)));   // + 1-plane exchange of u (overlapped with div)
-    WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
-    // corrector (:164-167); the 2-plane exchange of u is issued inside op_conv_diff (overlapped with its inner planes)
-    WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr, nullptr, true)));
-    WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, u, d.nu, d.perdir_mask)));   // (Flow.jl:164: Φ of the corrector)
-    WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd)));
+    WL_TRY((flow_project<T, D>(a, b, dt, 1.0, &n2[0], true, false, chain ? &corr_head : nullptr, &xbc, &xd, up)));   // + 1-plane exchange of u' (overlapped)
+    WL_TRY((op_bc_vec<T, D>(g, up, U, d.exitBC, d.perdir_mask, xd)));
+    // corrector (:164-167); the 2-plane exchange of u' is issued inside op_conv_diff (overlapped with its inner planes);
+    // σ's ghost cells: Φ of the corrector (Flow.jl:164), formed from u'; scale_u!(a,0.5) is folded into BDIM! #2 (MODE 2)
+    if (turns) {
+        if constexpr (D == 3) {
+            WL_TRY((op_conv_diff<T, D, true, false, 2>(g, f, up, d.nu, 0, u, V, dt, gc, gc != nullptr, nullptr, true, &fin2)));
+            WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, up, d.nu, 0)));
+            WL_TRY((op_bdim2_busy<T, 2>(g, u, up, f, V, mu0, mu1, a->busy, a->nbusy, a->nbusy_lo, a->nbusy_hi, xbc)));
+            xd = xbc.on != 0;
+        }
+    } else {
+        WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr, nullptr, true)));
+        WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, u, d.nu, d.perdir_mask)));
+        WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd)));
+    }
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
     WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true, chain, nullptr, &xbc, &xd)));
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
