@@ -13,7 +13,7 @@ T = np.float64 if (len(sys.argv) > 3 and sys.argv[3] == "f64") else np.float32
 for kv in os.environ.get("WL_OPTS", "").split(","):     # WL_OPTS=27:0,30:0 -> wl_set_option before the run
     if ":" in kv:
         S.set_option(int(kv.split(":")[0]), int(kv.split(":")[1]))
-sim = bench.sphere((size,) * 3, T)
+sim = (bench.donut if os.environ.get('WL_BODY') == 'donut' else bench.sphere)((size,) * 3, T)
 for _ in range(steps):
     S.sim_step(sim, remeasure=False)
 torch.cuda.synchronize()

@@ -260,6 +260,9 @@ struct wl_flow {
     Scratch sc;
     unsigned char *rowfree = nullptr;   // body-free row flags (wl_flow_update); nullptr until built
     unsigned char *rowbuf = nullptr;
+    unsigned char *segbuf = nullptr;    // the same per 64-cell segment of a row (3-D; wl_flow_update's scan only)
+    bool seg_valid = false;
+    const unsigned char *segfree() const { return (seg_valid && ctx().opt[3]) ? segbuf : nullptr; }
     int *busy = nullptr;                // compact list of the busy interior rows (j + n1*k), device
     int nbusy = 0;
     int nbusy_lo = 0, nbusy_hi = 0;      // how many of them lie in the first / last owned interior plane (the list is sorted by plane)
@@ -470,7 +473,7 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
     if (turns) {
         if constexpr (D == 3) {
             WL_TRY((op_conv_diff<T, D, true, false, 1>(g, f, u, d.nu, 0, u, V, dt, gp, gp != nullptr, nullptr, false, &fin1)));
-            WL_TRY((op_bdim2_busy<T, 1>(g, up, up, f, V, mu0, mu1, a->busy, a->nbusy, a->nbusy_lo, a->nbusy_hi, xbc)));   // + exchange of f
+            WL_TRY((op_bdim2_busy<T, 1>(g, up, up, f, V, mu0, mu1, a->busy, a->nbusy, a->nbusy_lo, a->nbusy_hi, xbc, a->segfree())));   // + exchange of f
             xd = xbc.on != 0;
         }
     } else {
@@ -479,7 +482,7 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
         // z⋅ϵ in the projection that follows (periodic runs only: elsewhere ϵ's ghosts are zero) and by maximum(a.σ) in CFL --
         // which sees the corrector's values, so a non-periodic run skips the predictor's.
         if (d.perdir_mask != 0) WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, u, d.nu, d.perdir_mask)));
-        WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd)));   // + exchange of f (overlapped)
+        WL_TRY((op_bdim2<T, D, 1>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd, a->segfree())));   // + exchange of f (overlapped)
     }
     WL_TRY((op_bc_vec<T, D>(g, up, U, d.exitBC, d.perdir_mask, xd)));
     if (d.exitBC) WL_TRY((op_exit_bc<T, D>(g, up, u0, U, dt, a->sc.partials, a->sc.st)));
@@ -494,13 +497,13 @@ static int flow_mom_step(wl_flow *a, wl_mg *b, double dt, const double *U, const
         if constexpr (D == 3) {
             WL_TRY((op_conv_diff<T, D, true, false, 2>(g, f, up, d.nu, 0, u, V, dt, gc, gc != nullptr, nullptr, true, &fin2)));
             WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, up, d.nu, 0)));
-            WL_TRY((op_bdim2_busy<T, 2>(g, u, up, f, V, mu0, mu1, a->busy, a->nbusy, a->nbusy_lo, a->nbusy_hi, xbc)));
+            WL_TRY((op_bdim2_busy<T, 2>(g, u, up, f, V, mu0, mu1, a->busy, a->nbusy, a->nbusy_lo, a->nbusy_hi, xbc, a->segfree())));
             xd = xbc.on != 0;
         }
     } else {
         WL_TRY((op_conv_diff<T, D, true>(g, f, u, d.nu, d.perdir_mask, u0, V, dt, gc, gc != nullptr, nullptr, true)));
         WL_TRY((op_sigma_ghosts<T, D>(g, (T *)d.sigma, u, d.nu, d.perdir_mask)));
-        WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd)));
+        WL_TRY((op_bdim2<T, D, 2>(g, u, f, V, mu0, mu1, a->rowfree, a->busy, a->nbusy, true, &xbc, &xd, a->segfree())));
     }
     WL_TRY((op_bc_vec<T, D>(g, u, U, d.exitBC, d.perdir_mask, xd)));
     WL_TRY((flow_project<T, D>(a, b, dt, 0.5, &n2[1], true, chain, nullptr, &xbc, &xd)));
@@ -702,7 +705,8 @@ static int flow_compact_busy(wl_flow *a, const G &g, int D) {
 }
 template <class T, int D> static int flow_update(wl_flow *a) {
     const G g = mkG(&a->d.g);
-    WL_TRY((op_rowflags<T, D>(g, (const T *)a->d.V, (const T *)a->d.mu0, (const T *)a->d.mu1, a->rowbuf, a->d.perdir_mask)));
+    WL_TRY((op_rowflags<T, D>(g, (const T *)a->d.V, (const T *)a->d.mu0, (const T *)a->d.mu1, a->rowbuf, a->d.perdir_mask, D == 3 ? a->segbuf : nullptr)));
+    a->seg_valid = (D == 3 && a->segbuf != nullptr);
     a->prev_valid = false;   // the arrays were written by someone else: the next native measure! rewrites every row
     return flow_compact_busy(a, g, D);
 }
@@ -769,6 +773,7 @@ template <class T, int D> static int measure_fill(wl_flow *a, const wl_body_desc
     WL_TRY((op_bc_vec<T, D>(g, (T *)a->d.V, zero, a->d.exitBC, a->d.perdir_mask)));
     WL_TRY((halo_exchange<T>(g, (T *)a->d.mu0, D, 2)));
     WL_TRY((halo_exchange<T>(g, (T *)a->d.V, D, 2)));
+    a->seg_valid = false;   // (the native measure! knows touched ROWS only: every segment of a busy row takes the general statement)
     hipLaunchKernelGGL((k_rowflags_touched<D>), dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, ctx().stream, g,
                        (const unsigned char *)a->touched, a->rowbuf, a->d.perdir_mask);
     WL_HIP(hipGetLastError());
@@ -1293,6 +1298,13 @@ int wl_flow_create(wl_flow **out, wl_dtype t, const wl_flow_desc *d) {
     if (rc) { delete a; return rc; }
     const size_t nrows = (size_t)d->g.n[1] * (size_t)(d->g.D > 2 ? d->g.n[2] : 1);
     if (wl_dev_alloc((void **)&a->rowbuf, nrows) != hipSuccess) { a->sc.release(); delete a; return fail(WL_E_STATE, "wl_dev_alloc(row flags)", __FILE__, __LINE__); }
+    if (d->g.D > 2) {
+        const size_t ntx = (size_t)(d->g.n[0] - 2 + 63) / 64;
+        if (wl_dev_alloc((void **)&a->segbuf, nrows * (ntx ? ntx : 1)) != hipSuccess) {
+            (void)hipFree(a->rowbuf); a->sc.release(); delete a;
+            return fail(WL_E_STATE, "wl_dev_alloc(segment flags)", __FILE__, __LINE__);
+        }
+    }
     *out = a;
     return 0;
 }
@@ -1301,6 +1313,7 @@ int wl_flow_destroy(wl_flow *a) {
     (void)hipStreamSynchronize(ctx().stream);
     a->sc.release();
     if (a->rowbuf) (void)hipFree(a->rowbuf);
+    if (a->segbuf) (void)hipFree(a->segbuf);
     if (a->busy) (void)hipFree(a->busy);
     if (a->rowcount) (void)hipFree(a->rowcount);
     if (a->rowoff) (void)hipFree(a->rowoff);

@@ -512,26 +512,35 @@ _Pragma("unroll")
 // scale_u!(a,0.5) (:166) -> u = 0.5*(u + ...), both roundings kept.
 // general BDIM! statement on a compact list of rows (row = j + n1*k), one wavefront per 64-cell row segment
 template <class T, int MODE>
+// seg (optional; wl_flow_update's scan): seg[row*ntx + s] != 0 -- the 64-cell segment s of that row holds no body cell (mu1 = 0,
+// V = 0, mu0 = 1 there): the statement is u (+)= f as in a body-free row, the 15 coefficient values and the 6 neighbours of f
+// are not read.  A torus puts a band cell into 21 % of the x-rows of a 512^3 grid, but into a third of their segments.
 __global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *uin, const T *f, const T *V, const T *mu0, const T *mu1,
-                                                    const int *rows, int nrows, int ntx, XBc<T> xb) {   // uin: the u that is read (MODE 0, 2)
+                                                    const int *rows, int nrows, int ntx, XBc<T> xb, const unsigned char *seg) {   // uin: the u that is read (MODE 0, 2)
     const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= (long)nrows * ntx) return;
     const int row = rows[w / ntx];
     const int i = 1 + (int)(w % ntx) * 64 + (threadIdx.x & 63);
+    const bool sfree = seg && __builtin_amdgcn_readfirstlane((int)seg[(long)row * ntx + (w % ntx)]) != 0;
     if (i > g.n[0] - 2) return;
     const int j = row % g.n[1], k = row / g.n[1];
     const long I = g.at(i, j, k);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const T *fc = f + (long)c * g.sc;
-        T s = 0;
-#pragma unroll
-        for (int jd = 0; jd < 3; ++jd) {
-            const T *m1 = mu1 + (long)(c + 3 * jd) * g.sc;
-            s += m1[I] * (fc[I + g.s[jd]] - fc[I - g.s[jd]]);
-        }
         const long q = I + (long)c * g.sc;
-        const double tmp = (0.5 * (double)s + (double)V[q]) + (double)(T)(mu0[q] * fc[I]);
+        double tmp;
+        if (sfree) {
+            tmp = (0.5 * 0.0 + 0.0) + (double)fc[I];
+        } else {
+            T s = 0;
+#pragma unroll
+            for (int jd = 0; jd < 3; ++jd) {
+                const T *m1 = mu1 + (long)(c + 3 * jd) * g.sc;
+                s += m1[I] * (fc[I + g.s[jd]] - fc[I - g.s[jd]]);
+            }
+            tmp = (0.5 * (double)s + (double)V[q]) + (double)(T)(mu0[q] * fc[I]);
+        }
         T val;
         if (MODE == 1) val = (T)(0.0 + tmp);
         else { const T un = (T)((double)uin[q] + tmp); val = (MODE == 2) ? (T)((double)un * 0.5) : un; }
@@ -548,14 +557,14 @@ __global__ __launch_bounds__(256) void k_bdim2_busy(G g, T *u, const T *uin, con
 // done (the list is sorted by plane: the first nlo rows lie in the first owned interior plane, the last nhi in the last one)
 template <class T, int MODE>
 int op_bdim2_busy(const G &g, T *u, const T *uin, const T *f, const T *V, const T *mu0, const T *mu1, const int *busy, int nbusy,
-                  int nlo, int nhi, const XBc<T> &xb) {
+                  int nlo, int nhi, const XBc<T> &xb, const unsigned char *seg = nullptr) {
     const int ntx = (g.n[0] - 2 + 63) / 64;
     auto rows = [&](int first, int n) -> int {
         if (n <= 0) return 0;
         const long nw = (long)n * ntx;
         Prof p(WL_K_BDIM, (long)n * (g.n[0] - 2));
         hipLaunchKernelGGL((k_bdim2_busy<T, MODE>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx().stream, g, u, uin, f, V, mu0, mu1,
-                           busy + first, n, ntx, xb);
+                           busy + first, n, ntx, xb, seg);
         return (int)hipGetLastError();
     };
     Comm *cm = ctx().comm;
@@ -573,7 +582,8 @@ int op_bdim2_busy(const G &g, T *u, const T *uin, const T *f, const T *V, const 
 // over the body-free rows (which reads no neighbour of f) runs while it is in flight, the busy rows after it.
 template <class T, int D, int MODE>
 int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu1, const unsigned char *rowfree = nullptr,
-             const int *busy = nullptr, int nbusy = 0, bool exchange_f = false, const XBc<T> *xbc = nullptr, bool *xdone = nullptr) {
+             const int *busy = nullptr, int nbusy = 0, bool exchange_f = false, const XBc<T> *xbc = nullptr, bool *xdone = nullptr,
+             const unsigned char *seg = nullptr) {
     const G gg = g;
     if (!ctx().opt[3]) rowfree = nullptr;
     if (xdone) *xdone = false;
@@ -593,7 +603,7 @@ int op_bdim2(const G &g, T *u, const T *f, const T *V, const T *mu0, const T *mu
                 const long nw = (long)nbusy * ntx;
                 Prof p(WL_K_BDIM, (long)nbusy * (g.n[0] - 2));
                 hipLaunchKernelGGL((k_bdim2_busy<T, MODE>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx().stream, g, u, (const T *)u, f, V,
-                                   mu0, mu1, busy, nbusy, ntx, xb);
+                                   mu0, mu1, busy, nbusy, ntx, xb, seg);
                 return (int)hipGetLastError();
             };
             const int rc = launch_rowvec<T, 0, false>(WL_K_BDIM, g,
@@ -673,7 +683,8 @@ _Pragma("unroll")
 
 // body-free row flags (see op_bdim2): one wavefront scans one x-row of the 15 coefficient arrays
 template <class T, int D>
-__global__ __launch_bounds__(256) void k_rowflags(G g, const T *V, const T *mu0, const T *mu1, unsigned char *flags, bool xper) {
+__global__ __launch_bounds__(256) void k_rowflags(G g, const T *V, const T *mu0, const T *mu1, unsigned char *flags, unsigned char *seg,
+                                                  bool xper) {   // seg (optional): the same test per 64-cell segment of the row
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long nrows = (long)g.n[1] * (D > 2 ? g.n[2] : 1);
@@ -681,25 +692,33 @@ __global__ __launch_bounds__(256) void k_rowflags(G g, const T *V, const T *mu0,
     const int j = (int)(row % g.n[1]), k = (int)(row / g.n[1]);
     const long base = g.at(0, j, k);
     bool busy = false;
+    const int ntx = (g.n[0] - 2 + 63) / 64;
     // interior cells only (BDIM! does not touch ghosts).  With a non-periodic x the inflow face (i=1, component x)
     // carries the zero of BC!(mu0,0) (Flow.jl:119) in EVERY row; inside mom_step! the BC!(u) that follows BDIM!
     // (Flow.jl:159,166) overwrites u_x on that plane, so its mu0 is not allowed to mark the row busy.
-    for (int i = 1 + lane; i <= g.n[0] - 2; i += 64) {
-        const long I = base + i;
-        for (int c = 0; c < D; ++c) {
-            const bool inflow_face = (i == 1 && c == 0 && !xper);
-            busy = busy || (V[I + (long)c * g.sc] != (T)0) || (!inflow_face && mu0[I + (long)c * g.sc] != (T)1);
-            for (int d = 0; d < D; ++d) busy = busy || (mu1[I + (long)(c + D * d) * g.sc] != (T)0);
+    for (int q = 0; q < ntx; ++q) {              // (every lane takes part in every ballot)
+        const int i = 1 + lane + 64 * q;
+        bool b = false;
+        if (i <= g.n[0] - 2) {
+            const long I = base + i;
+            for (int c = 0; c < D; ++c) {
+                const bool inflow_face = (i == 1 && c == 0 && !xper);
+                b = b || (V[I + (long)c * g.sc] != (T)0) || (!inflow_face && mu0[I + (long)c * g.sc] != (T)1);
+                for (int d = 0; d < D; ++d) b = b || (mu1[I + (long)(c + D * d) * g.sc] != (T)0);
+            }
         }
+        const unsigned long long anyq = __ballot(b);
+        if (seg && lane == 0) seg[row * ntx + q] = anyq ? 0 : 1;
+        busy = busy || b;
     }
     const unsigned long long any = __ballot(busy);
     if (lane == 0) flags[j + (long)g.n[1] * k] = any ? 0 : 1;
 }
 template <class T, int D>
-int op_rowflags(const G &g, const T *V, const T *mu0, const T *mu1, unsigned char *flags, int permask) {
+int op_rowflags(const G &g, const T *V, const T *mu0, const T *mu1, unsigned char *flags, int permask, unsigned char *seg = nullptr) {
     const long nrows = (long)g.n[1] * (D > 2 ? g.n[2] : 1);
     Prof p(WL_K_MISC, g.cells());
-    hipLaunchKernelGGL((k_rowflags<T, D>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ctx().stream, g, V, mu0, mu1, flags,
+    hipLaunchKernelGGL((k_rowflags<T, D>), dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ctx().stream, g, V, mu0, mu1, flags, seg,
                        (bool)(permask & 1));
     return (int)hipGetLastError();
 }
