@@ -324,7 +324,9 @@ def accel_tuple(g, U, dt: Sequence[float], D: int):
 # --------------------------------------------------------------------------- Flow.jl
 
 class Flow:
-    """src/Flow.jl:92-122.  Fields: u, u0, f, V, mu0 (Ng...,D); mu1 (Ng...,D,D); p, sigma (Ng...)."""
+    """src/Flow.jl:92-122.  Fields: u, u0, f, V, mu0 (Ng...,D); mu1 (Ng...,D,D); p, sigma (Ng...).
+    u0 is scratch between steps, as in the reference (mom_step! overwrites it before reading it, Flow.jl:154): after a step of a
+    3-D run without periodic directions / convective exit it holds the predictor's velocity, not the old one (wl_set_option(27))."""
 
     def __init__(self, N, U, *, dt=0.25, nu=0.0, g=None, ulam=None, perdir=(), exitBC=False, T=np.float64,
                  device="cuda:0", padded=True, slab=None):
